@@ -1,0 +1,182 @@
+/* yolohip.h -- C ABI of libyolohip.so, the MI355X (gfx950) kernels behind the YOLO hot path.
+ *
+ * The reference (KhaledSharif/yolo-from-scratch) has no FFI layer: its hot path is the Python
+ * surface of train.py, which dispatches to ATen.  Each entry point below replaces the ATen ops one
+ * reference call site dispatches to; the citation after "replaces" is that call site.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless its comment says HOST (small
+ *     configuration arrays: anchors, grid sizes, arrays of device pointers, the op list); the
+ *     library never allocates or frees device memory and keeps no pointer after returning;
+ *   - activations are NHWC fp32; a tensor argument is (ptr, ld) where ld = floats per pixel of the
+ *     buffer the view lives in (channel-slice views of a concat buffer have ld > C);
+ *   - calls are asynchronous and ordered on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises the device or the stream; all are hipGraph-capturable;
+ *   - return 0 on success, a positive hipError_t or a negative YH_E_* otherwise; the message is
+ *     available from yh_last_error(); no C++ exception crosses this boundary.
+ */
+#ifndef YOLOHIP_H
+#define YOLOHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_E_BADARG (-1)
+#define YH_E_UNSUPPORTED (-2)
+#define YH_E_WORKSPACE (-3)
+
+int yh_version(void);
+const char *yh_last_error(void);
+
+/* ---- layout ------------------------------------------------------------------------------- */
+/* NCHW (B,C,H,W) -> NHWC with ld floats per pixel (channels >= C are zero filled up to cpad).
+ * replaces: the NCHW image batch handed to YOLO.forward (train.py:568). */
+int yh_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, int ld, int cpad, void *stream);
+/* NHWC view (C channels, ld) -> NCHW contiguous; `accumulate` adds into dst. */
+int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, int ld, int accumulate, void *stream);
+/* OIHW weights -> forward pack [kh*kw][Cin_pad][ldwf] and backward-data pack [kh*kw][Cout][ldwb];
+ * either destination may be NULL.  Cin_pad >= Cin rows beyond Cin are zero (stem: 3 -> 4). */
+int yh_pack_weights(const float *oihw, float *wf, float *wb, int Cout, int Cin, int k, int cin_pad, int ldwf,
+                    int ldwb, void *stream);
+
+/* ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) ---------------------------------- */
+/* Forward: y = conv(x, w) (+ bias); square kernel k in {1,3}, stride s in {1,2}, pad k/2.
+ * If bn_partials != NULL the epilogue also writes per-workgroup per-channel sum / sum of squares
+ * of y: bn_partials[(blk*2 + {0,1})*Cout + c], blk < yh_conv_fwd_blocks(...).
+ * replaces: nn.Conv2d.forward inside ConvBlock (train.py:260,265), the inline stem/downsample
+ * convs (train.py:402-418), SPPF convs (236,240) and head output convs (455,460,465). */
+int yh_conv_fwd(const float *x, int ldx, const float *wf, int ldwf, const float *bias, float *y, int ldy,
+                float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
+int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s);
+/* Backward-data: dx (+)= conv_transpose(dy, w).  replaces: aten::convolution_backward (input
+ * gradient) reached from loss.backward() (train.py:913). */
+int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi,
+                     int Wi, int Cin, int Cout, int k, int s, int accumulate, void *stream);
+/* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction
+ * through `ws` (ws_floats >= yh_conv_bwd_weight_ws(...)).  Writes OIHW (Cin_real input channels)
+ * into dw.  replaces: aten::convolution_backward (weight gradient), train.py:913. */
+int yh_conv_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws,
+                       int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k, int s,
+                       void *stream);
+int64_t yh_conv_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s);
+/* Per-channel column sum of an NHWC view (bias gradient); ws_floats >= yh_colsum_ws(M, C). */
+int yh_colsum(const float *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream);
+int64_t yh_colsum_ws(int64_t M, int C);
+
+/* ---- BatchNorm2d + SiLU ----------------------------------------------------------------------- */
+/* Reduce conv-epilogue partials to batch mean / biased variance; write scale = gamma*invstd and
+ * shift = beta - mean*scale into coef[0..C) / coef[C..2C), mean / invstd into coef[2C..4C);
+ * update running_mean / running_var (unbiased) with `momentum` when running_mean != NULL.
+ * replaces: nn.BatchNorm2d training-mode statistics (train.py:261,265; torch native_batch_norm). */
+int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
+                   float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
+                   void *stream);
+/* Inference coefficients from running statistics (BN folded to scale/shift). */
+int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                    float eps, float *coef, int C, void *stream);
+/* a = silu(y*scale + shift) (+ residual); optional nearest x2 upsample on write (out is then
+ * (B,2H,2W)).  replaces: BatchNorm2d.forward + nn.SiLU (train.py:265), the Bottleneck residual add
+ * (train.py:306), nn.Upsample (train.py:431,436) and the torch.cat copies (train.py:250,293,585-598)
+ * because `out` may be a channel slice of the concat buffer. */
+int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
+                   int ldo, int64_t M, int C, int H, int W, int upsample, void *stream);
+/* Backward stage 1: per-channel partial sums of dz and dz*xhat where dz = da*silu'(z);
+ * da is read with a 2x2 sum when `upsample`.  partials: [nblk][2][C], nblk = yh_bn_bwd_blocks(M). */
+int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef, float *partials,
+                          int64_t M, int C, int H, int W, int upsample, void *stream);
+int yh_bn_bwd_blocks(int64_t M, int C);
+/* Backward stage 2: dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta written from the
+ * partials; if dres != NULL the incoming da is also routed to the residual branch
+ * (dres = da or dres += da).  replaces: native_batch_norm_backward + silu_backward (train.py:913). */
+int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, int ldy, const float *coef,
+                         const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
+                         float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C,
+                         int H, int W, int upsample, void *stream);
+
+/* ---- SPPF max-pool 5x5 / stride 1 / pad 2 ------------------------------------------------------ */
+/* replaces: nn.MaxPool2d(5,1,2) (train.py:239,246-248); argmax (window tap 0..24, first max wins)
+ * is kept for the backward pass. */
+int yh_maxpool5_fwd(const float *x, int ldx, float *y, int ldy, uint8_t *argmax, int B, int H, int W, int C,
+                    void *stream);
+/* dx += route(dy) (gather form, deterministic). */
+int yh_maxpool5_bwd(const float *dy, int lddy, const uint8_t *argmax, float *dx, int lddx, int B, int H, int W,
+                    int C, void *stream);
+
+/* ---- loss: decode + CIoU + BCE, three scales, forward and backward in one pass ----------------- */
+/* pred[s], target[s]: (B,G_s,G_s,3,5+nc) contiguous, G_s = grid[s] (pred/target/dpred/grid are HOST
+ * arrays of device pointers / ints); anchors: HOST, 3x3x2 floats (pixels), captured by value.
+ * out[0..4) = total, sum box, sum obj (unweighted), sum cls (train.py:886); out[4+3s..] = per-scale
+ * box/obj/cls.  dpred[s] (may be NULL -> forward only) receives d total / d pred[s] * grad_scale.
+ * ws: >= yh_loss_ws(...) floats, 8-byte aligned.  loss_img_size is the decode img_size (reference: always 640, Q1).
+ * replaces: decode_predictions + ciou_loss + yolo_loss + yolo_loss_multiscale and their autograd
+ * (train.py:634-886, 909, 913). */
+int yh_yolo_loss(const float *const pred[3], const float *const target[3], float *const dpred[3],
+                 const float *anchors, const int grid[3], int B, int nc, float loss_img_size, float grad_scale,
+                 float *out, float *ws, void *stream);
+int64_t yh_loss_ws(const int grid[3], int B);
+/* Standalone pieces of the same math for the reference's public functions (anchors3x2: HOST).
+ * yh_ciou: ws >= 2*ceil(N/256) floats, 8-byte aligned; N must be > 0. */
+int yh_decode(const float *raw, float *out, const float *anchors3x2, int B, int GH, int GW, int nc,
+              float img_size, void *stream);                               /* train.py:712-779 */
+int yh_decode_bwd(const float *raw, const float *dout, float *draw, const float *anchors3x2, int B, int GH,
+                  int GW, int nc, float img_size, void *stream);
+int yh_ciou(const float *pred, const float *tgt, float *dpred, int64_t N, float eps, float grad_scale,
+            float *loss_out, float *ws, void *stream);                     /* train.py:634-710 */
+
+/* ---- inference post-process --------------------------------------------------------------------- */
+/* Candidate extraction of predict() (train.py:1152-1229) for one image: keeps cells with
+ * sigmoid(obj) > conf_thr in scale-major, row-major (i,j,a) order.  boxes (cap,4) corners in
+ * original-image pixels, scores (cap), classes (cap) int32, count[0] = M (may exceed cap: the
+ * caller must check).  ws: >= yh_candidates_ws(grid) ints. */
+int yh_candidates(const float *const pred[3], const float *anchors, const int grid[3], int nc, float img_size,
+                  float conf_thr, float pad_left, float pad_top, float scale, float *boxes, float *scores,
+                  int32_t *classes, int32_t *count, int cap, int32_t *ws, void *stream);
+int64_t yh_candidates_ws(const int grid[3]);
+/* Class-aware greedy NMS = torchvision.ops.batched_nms as called at train.py:1232-1233: stable
+ * descending score order, suppress IoU > thr within a class.  M is read from count[0] on the
+ * device (clamped to cap).  keep (cap) int32 receives kept candidate indices in descending score
+ * order, nkeep[0] their number.  ws: >= yh_nms_ws(cap) bytes. */
+int yh_nms(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count, int cap,
+           float iou_thr, int32_t *keep, int32_t *nkeep, void *ws, void *stream);
+int64_t yh_nms_ws(int cap);
+
+/* ---- optimiser: global-norm clip + Adam over flat buffers -------------------------------------- */
+/* norm_out[0] = ||g||_2 (fp32), deterministic two-stage reduce; ws >= yh_sqnorm_ws(n) doubles.
+ * replaces: torch.nn.utils.clip_grad_norm_ (train.py:916). */
+int yh_grad_sqnorm(const float *g, int64_t n, float *norm_out, double *ws, void *stream);
+int64_t yh_sqnorm_ws(int64_t n);
+/* g *= min(1, max_norm/(norm+1e-6)) (skipped when max_norm <= 0 or norm == NULL), then one Adam
+ * step (torch.optim.Adam defaults, step is 1-based).  replaces: train.py:916-918. */
+int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int step, float max_norm, const float *norm, void *stream);
+
+/* ---- small utilities (stream-ordered) --------------------------------------------------------------- */
+int yh_memset(void *p, int value, int64_t bytes, void *stream);
+/* *p += v on the device (BatchNorm2d.num_batches_tracked). */
+int yh_add_int64(int64_t *p, int64_t v, void *stream);
+
+/* ---- op-list executor --------------------------------------------------------------------------- */
+/* One record per kernel launch; `kind` selects the entry point above, the arrays carry its
+ * arguments in declaration order (pointers in p[], ints in i[], floats in f[]). */
+typedef struct yh_op {
+    int32_t kind;
+    int32_t i[20];
+    float f[4];
+    void *p[12];
+    int64_t l[2];
+} yh_op;
+enum {
+    YH_OP_NCHW_TO_NHWC = 1, YH_OP_NHWC_TO_NCHW, YH_OP_PACK_WEIGHTS, YH_OP_CONV_FWD, YH_OP_CONV_BWD_DATA,
+    YH_OP_CONV_BWD_WEIGHT, YH_OP_COLSUM, YH_OP_BN_FINALIZE, YH_OP_BN_EVAL_COEF, YH_OP_BN_SILU_FWD,
+    YH_OP_BN_SILU_BWD_REDUCE, YH_OP_BN_SILU_BWD_APPLY, YH_OP_MAXPOOL5_FWD, YH_OP_MAXPOOL5_BWD, YH_OP_MEMSET,
+    YH_OP_ADD_INT64
+};
+/* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
+ * (failing index in *failed when non-NULL). */
+int yh_run(const yh_op *ops, int n, void *stream, int *failed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+// Error reporting, version and the op-list executor of libyolohip.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void yh_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *yh_last_error(void) { return g_err; }
+extern "C" int yh_version(void) { return 100; }
+
+extern "C" int yh_memset(void *p, int value, int64_t bytes, void *stream) {
+    YH_REQUIRE(p && bytes >= 0, "memset: bad argument");
+    YH_HIP(hipMemsetAsync(p, value, (size_t)bytes, (hipStream_t)stream));
+    return 0;
+}
+
+// Dispatch one record to its entry point; argument order = declaration order in yolohip.h.
+static int run_one(const yh_op &o, void *st) {
+    const int32_t *i = o.i;
+    const float *f = o.f;
+    void *const *p = o.p;
+    switch (o.kind) {
+        case YH_OP_NCHW_TO_NHWC:
+            return yh_nchw_to_nhwc((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], i[4], i[5], st);
+        case YH_OP_NHWC_TO_NCHW:
+            return yh_nhwc_to_nchw((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], i[4], i[5], st);
+        case YH_OP_PACK_WEIGHTS:
+            return yh_pack_weights((const float *)p[0], (float *)p[1], (float *)p[2], i[0], i[1], i[2], i[3], i[4], i[5], st);
+        case YH_OP_CONV_FWD:
+            return yh_conv_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3],
+                               i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
+        case YH_OP_CONV_BWD_DATA:
+            return yh_conv_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
+                                    i[5], i[6], i[7], i[8], i[9], i[10], st);
+        case YH_OP_CONV_BWD_WEIGHT:
+            return yh_conv_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
+                                      o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
+        case YH_OP_COLSUM:
+            return yh_colsum((const float *)p[0], i[0], o.l[0], i[1], (float *)p[1], (float *)p[2], st);
+        case YH_OP_BN_FINALIZE:
+            return yh_bn_finalize((const float *)p[0], i[0], o.l[0], (const float *)p[1], (const float *)p[2],
+                                  (float *)p[3], (float *)p[4], f[0], f[1], (float *)p[5], i[1], st);
+        case YH_OP_BN_EVAL_COEF:
+            return yh_bn_eval_coef((const float *)p[0], (const float *)p[1], (const float *)p[2], (const float *)p[3], f[0],
+                                   (float *)p[4], i[0], st);
+        case YH_OP_BN_SILU_FWD:
+            return yh_bn_silu_fwd((const float *)p[0], i[0], (const float *)p[1], (const float *)p[2], i[1], (float *)p[3],
+                                  i[2], o.l[0], i[3], i[4], i[5], i[6], st);
+        case YH_OP_BN_SILU_BWD_REDUCE:
+            return yh_bn_silu_bwd_reduce((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
+                                         (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], st);
+        case YH_OP_BN_SILU_BWD_APPLY:
+            return yh_bn_silu_bwd_apply((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
+                                        (const float *)p[3], i[2], (const float *)p[4], (float *)p[5], (float *)p[6],
+                                        (float *)p[7], i[3], (float *)p[8], i[4], i[5], o.l[0], i[6], i[7], i[8], i[9], st);
+        case YH_OP_MAXPOOL5_FWD:
+            return yh_maxpool5_fwd((const float *)p[0], i[0], (float *)p[1], i[1], (uint8_t *)p[2], i[2], i[3], i[4], i[5], st);
+        case YH_OP_MAXPOOL5_BWD:
+            return yh_maxpool5_bwd((const float *)p[0], i[0], (const uint8_t *)p[1], (float *)p[2], i[1], i[2], i[3], i[4],
+                                   i[5], st);
+        case YH_OP_MEMSET:
+            return yh_memset(p[0], i[0], o.l[0], st);
+        case YH_OP_ADD_INT64:
+            return yh_add_int64((int64_t *)p[0], o.l[0], st);
+        default:
+            yh_set_error("yh_run: unknown op kind %d", o.kind);
+            return YH_E_BADARG;
+    }
+}
+
+extern "C" int yh_run(const yh_op *ops, int n, void *stream, int *failed) {
+    YH_REQUIRE(ops || n == 0, "yh_run: null op list");
+    for (int k = 0; k < n; ++k) {
+        int rc = run_one(ops[k], stream);
+        if (rc) {
+            if (failed) *failed = k;
+            return rc;
+        }
+    }
+    return 0;
+}

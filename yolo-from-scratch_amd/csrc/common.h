@@ -1,0 +1,57 @@
+// Shared helpers for libyolohip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/yolohip.h"
+
+void yh_set_error(const char *fmt, ...);
+
+#define YH_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) {                                         \
+            yh_set_error(__VA_ARGS__);                         \
+            return YH_E_BADARG;                                \
+        }                                                      \
+    } while (0)
+
+// Check the launch that was just enqueued (no synchronisation).
+#define YH_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            yh_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+#define YH_HIP(call)                                                                 \
+    do {                                                                             \
+        hipError_t e__ = (call);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            yh_set_error("%s: %s", #call, hipGetErrorString(e__));                   \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// accurate exp (not __expf): parity with the CPU reference is 1e-4 relative on losses
+__device__ __forceinline__ float yh_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// 64-lane butterfly sum; every lane ends with the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

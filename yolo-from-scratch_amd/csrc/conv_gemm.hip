@@ -1,0 +1,334 @@
+// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (gfx950), NHWC fp32.
+//
+// One "gather GEMM" kernel serves the forward convolution and the backward-data convolution:
+//     out[p][n] (+)= sum_{tap, c} in[gather(p, tap)][c] * w[tap][c][n]       (+ bias[n])
+// p runs over an output lattice (B x Yo x Xo) that may be a strided sub-lattice of the output
+// tensor (the four parity classes of a stride-2 backward-data pass), gather(p, tap) is the input
+// pixel (y*sy + dy[tap], x*sx + dx[tap]) and is skipped (zero) when it falls outside the input.
+//
+// GEMM view: M = B*Yo*Xo pixels, N = output channels, K = taps*Cin.  A workgroup of 4 waves owns a
+// BM x BN tile; K is walked in chunks of 32 staged through LDS (register-staged double buffer).
+// MFMA operand maps (cdna guide section 3): A lane l = A[row l&31][k l>>5], B lane l = B[k l>>5][col l&31],
+// D reg r of lane l = D[row (r&3)+8(r>>2)+4(l>>5)][col l&31]: output channels sit on lanes, so a
+// store instruction writes 128 contiguous bytes per half wave and the BatchNorm column sums are
+// lane-local.  The A tile is kept [pixel][k] with a 36-float row stride: a lane's four consecutive
+// k values come from one conflict-free ds_read_b128 and feed four MFMAs (the k order inside a
+// chunk is permuted consistently for A and B, which a sum over k does not care about).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDA = BK + 4;
+
+struct GatherGemm {
+    const float *in, *w, *bias;
+    float *out, *stats;
+    int Hi, Wi, ldi, Cin;
+    int ldw;
+    int Ho_f, Wo_f, ldo, N;
+    int B, Yo, Xo, M;
+    int osy, osx, ooy, oox;
+    int sy, sx;
+    int nTaps, Ktot;
+    int accumulate, dense;
+    int tap_dy[9], tap_dx[9], tap_w[9];
+};
+
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AROWS = BM / 32;
+    constexpr int BQ = BN / 4;
+    constexpr int BROWS = 256 / BQ;
+    constexpr int BPASS = BK / BROWS;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BPASS >= 1, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                          // [2][BM][LDA]
+    float *Bs = smem + 2 * BM * LDA;           // [2][BK][BN]
+    int *tapt = (int *)(Bs + 2 * BK * BN);     // [3][9]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (t < 9) {
+        tapt[t] = g.tap_dy[t];
+        tapt[9 + t] = g.tap_dx[t];
+        tapt[18 + t] = g.tap_w[t];
+    }
+
+    // per-thread A rows: r = (t>>3) + 32*i, float4 column kq = t&7
+    const int kq = t & 7;
+    int rbase[AROWS], riy[AROWS], rix[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        int m = m0 + (t >> 3) + 32 * i;
+        if (m < g.M) {
+            int x = m % g.Xo, q = m / g.Xo;
+            int y = q % g.Yo, b = q / g.Yo;
+            rbase[i] = b * g.Hi * g.Wi;
+            riy[i] = y * g.sy;
+            rix[i] = x * g.sx;
+        } else {
+            rbase[i] = 0;
+            riy[i] = -(1 << 20);
+            rix[i] = 0;
+        }
+    }
+    __syncthreads();
+
+    f32x4 ra[AROWS], rb[BPASS];
+    auto load_tiles = [&](int c) {
+        const int k = c * BK + 4 * kq;
+        if (VEC == 4) {
+            if (k < g.Ktot) {
+                int tap = k / g.Cin, ci = k - tap * g.Cin;
+                int dy = tapt[tap], dx = tapt[9 + tap];
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    int iy = riy[i] + dy, ix = rix[i] + dx;
+                    bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                    ra[i] = ok ? *(const f32x4 *)(g.in + ((size_t)(rbase[i] + iy * g.Wi + ix) * g.ldi + ci))
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int ke = k + e;
+                if (ke < g.Ktot) {
+                    int tap = ke / g.Cin, ci = ke - tap * g.Cin;
+                    int dy = tapt[tap], dx = tapt[9 + tap];
+#pragma unroll
+                    for (int i = 0; i < AROWS; ++i) {
+                        int iy = riy[i] + dy, ix = rix[i] + dx;
+                        bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                        if (ok) ra[i][e] = g.in[(size_t)(rbase[i] + iy * g.Wi + ix) * g.ldi + ci];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int kr = c * BK + t / BQ + p * BROWS;
+            int n = n0 + 4 * (t % BQ);
+            if (kr < g.Ktot && n < g.ldw) {
+                int tap = kr / g.Cin, ci = kr - tap * g.Cin;
+                rb[p] = *(const f32x4 *)(g.w + (size_t)(tapt[18 + tap] * g.Cin + ci) * g.ldw + n);
+            } else {
+                rb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float *a = As + buf * BM * LDA;
+        float *b = Bs + buf * BK * BN;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) *(f32x4 *)(a + ((t >> 3) + 32 * i) * LDA + 4 * kq) = ra[i];
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) *(f32x4 *)(b + (t / BQ + p * BROWS) * BN + 4 * (t % BQ)) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (g.Ktot + BK - 1) / BK;
+    const int lr = lane & 31, lh = lane >> 5;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_tiles(c + 1);
+        const float *a = As + buf * BM * LDA + (wm * TM * 32 + lr) * LDA + 4 * lh;
+        const float *b = Bs + buf * BK * BN + (4 * lh) * BN + wn * TN * 32 + lr;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            f32x4 av[TM];
+            float bv[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4 *)(a + i * 32 * LDA + kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = b[(kk + e) * BN + j * 32];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, optional accumulate, store, optional BatchNorm partial sums ----------
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + wn * TN * 32 + j * 32 + lr;
+        bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= g.M) continue;
+            size_t opix;
+            if (g.dense) {
+                opix = (size_t)m;
+            } else {
+                int x = m % g.Xo, q = m / g.Xo;
+                int y = q % g.Yo, b = q / g.Yo;
+                opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
+            }
+            float *orow = g.out + opix * g.ldo;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + wn * TN * 32 + j * 32 + lr;
+                if (n < g.N) {
+                    float v = acc[i][j][r] + bias_v[j];
+                    if (g.accumulate) v += orow[n];
+                    orow[n] = v;
+                    csum[j] += v;
+                    csq[j] += v * v;
+                }
+            }
+        }
+    }
+    if (g.stats) {
+        float *red = smem;   // [WM][BN][2]; the main loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32);
+            float q = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) {
+                int col = wn * TN * 32 + j * 32 + lr;
+                red[(wm * BN + col) * 2 + 0] = s;
+                red[(wm * BN + col) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < g.N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s += red[(w * BN + t) * 2 + 0];
+                q += red[(w * BN + t) * 2 + 1];
+            }
+            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = s;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = q;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int VEC>
+int launch_cfg(const GatherGemm &g, hipStream_t st) {
+    constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 27 * sizeof(int);
+    static bool attr_set = false;
+    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC>;
+    if (!attr_set) {
+        YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
+    YH_CHECK_LAUNCH("gather_gemm");
+    return 0;
+}
+
+constexpr int kBM = 128;
+
+int launch(const GatherGemm &g, hipStream_t st) {
+    YH_REQUIRE(g.M > 0 && g.N > 0 && g.Ktot > 0, "gather_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.Ktot);
+    YH_REQUIRE(g.ldw % 4 == 0 && g.ldw >= g.N, "gather_gemm: weight row stride %d must be a multiple of 4 and >= N=%d",
+               g.ldw, g.N);
+    YH_REQUIRE(((uintptr_t)g.w & 15) == 0, "gather_gemm: weights must be 16-byte aligned");
+    const bool vec = (g.Cin % 4 == 0) && (g.ldi % 4 == 0) && (((uintptr_t)g.in & 15) == 0);
+    if (g.N <= 32) return vec ? launch_cfg<kBM, 32, 4, 1, 4>(g, st) : launch_cfg<kBM, 32, 4, 1, 1>(g, st);
+    if (g.N <= 64) return vec ? launch_cfg<kBM, 64, 2, 2, 4>(g, st) : launch_cfg<kBM, 64, 2, 2, 1>(g, st);
+    return vec ? launch_cfg<kBM, 128, 2, 2, 4>(g, st) : launch_cfg<kBM, 128, 2, 2, 1>(g, st);
+}
+
+}  // namespace
+
+extern "C" int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s) {
+    (void)Cout;
+    int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
+    return cdiv(B * Ho * Wo, kBM);
+}
+
+extern "C" int yh_conv_fwd(const float *x, int ldx, const float *wf, int ldwf, const float *bias, float *y, int ldy,
+                           float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s,
+                           void *stream) {
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_fwd: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_fwd: bad argument");
+    YH_REQUIRE(ldx >= Cin && ldy >= Cout, "conv_fwd: ld smaller than channel count");
+    YH_REQUIRE((int64_t)B * Hi * Wi * (int64_t)ldx < (1ll << 31), "conv_fwd: input too large for 32-bit pixel index");
+    GatherGemm g{};
+    const int p = k / 2;
+    g.in = x; g.w = wf; g.bias = bias; g.out = y; g.stats = bn_partials;
+    g.Hi = Hi; g.Wi = Wi; g.ldi = ldx; g.Cin = Cin; g.ldw = ldwf;
+    g.Ho_f = (Hi + 2 * p - k) / s + 1; g.Wo_f = (Wi + 2 * p - k) / s + 1; g.ldo = ldy; g.N = Cout;
+    g.B = B; g.Yo = g.Ho_f; g.Xo = g.Wo_f; g.M = B * g.Yo * g.Xo;
+    g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
+    g.nTaps = k * k; g.Ktot = g.nTaps * Cin; g.accumulate = 0; g.dense = 1;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            int t = kh * k + kw;
+            g.tap_dy[t] = kh - p; g.tap_dx[t] = kw - p; g.tap_w[t] = t;
+        }
+    return launch(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B,
+                                int Hi, int Wi, int Cin, int Cout, int k, int s, int accumulate, void *stream) {
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_bwd_data: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(dy && wb && dx && B > 0 && Cin > 0 && Cout > 0, "conv_bwd_data: bad argument");
+    YH_REQUIRE(lddy >= Cout && lddx >= Cin, "conv_bwd_data: ld smaller than channel count");
+    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
+    YH_REQUIRE(!(k == 1 && s == 2), "conv_bwd_data: 1x1 stride-2 is not used by this network");
+    // one launch per residue class of the input pixel modulo the stride
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            GatherGemm g{};
+            g.in = dy; g.w = wb; g.bias = nullptr; g.out = dx; g.stats = nullptr;
+            g.Hi = Ho; g.Wi = Wo; g.ldi = lddy; g.Cin = Cout; g.ldw = ldwb;
+            g.Ho_f = Hi; g.Wo_f = Wi; g.ldo = lddx; g.N = Cin;
+            g.B = B; g.Yo = (Hi - ph + s - 1) / s; g.Xo = (Wi - pw + s - 1) / s; g.M = B * g.Yo * g.Xo;
+            g.osy = g.osx = s; g.ooy = ph; g.oox = pw; g.sy = g.sx = 1;
+            g.accumulate = accumulate; g.dense = (s == 1);
+            int nt = 0;
+            for (int kh = 0; kh < k; ++kh) {
+                if ((ph + p - kh) % s != 0) continue;
+                for (int kw = 0; kw < k; ++kw) {
+                    if ((pw + p - kw) % s != 0) continue;
+                    g.tap_dy[nt] = (ph + p - kh) / s; g.tap_dx[nt] = (pw + p - kw) / s; g.tap_w[nt] = kh * k + kw;
+                    ++nt;
+                }
+            }
+            YH_REQUIRE(nt > 0, "conv_bwd_data: residue class without taps");
+            g.nTaps = nt; g.Ktot = nt * Cout;
+            if (g.M == 0) continue;
+            int rc = launch(g, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    return 0;
+}

@@ -1,0 +1,332 @@
+// Inference post-process of predict(): order-preserving candidate compaction and class-aware NMS.
+//
+// NMS index selection must match the CPU definition bit for bit, so this file is compiled with
+// floating-point contraction OFF (no FMA fusion): IoU is evaluated as
+//   inter / ((area_i + area_j) - inter) > thr      with area = (x2-x1)*(y2-y1),
+// one IEEE rounding per operation, exactly as torchvision's CPU kernel does.
+//
+// Pipeline (all sizes are device-side: M is read from count[0], launches are sized by `cap`):
+//   1. keys = (descending-orderable score, candidate index) -> bitonic sort by one workgroup
+//      (LDS when the padded size fits 16384 keys, else in the workspace); ties in score keep the
+//      lower candidate index first = a stable descending sort.
+//   2. gather boxes/classes into sorted order.
+//   3. 64x64-tiled suppression bit matrix (upper triangle): bit (i, j) = j > i, same class, IoU > thr.
+//   4. one workgroup resolves the greedy scan: per 64-box block one wave walks the diagonal word in
+//      registers, then every thread ORs the kept rows into the removal word it owns.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+struct CandArgs {
+    const float *pred[3];
+    float anchors[18];
+    int grid[3];
+    int cell_begin[4];
+    int nc, cap;
+    float img, thr, pad_left, pad_top, scale;
+    float *boxes, *scores;
+    int32_t *classes, *count, *blk;   // blk: [nblk] counts then [nblk] offsets
+    int nblk;
+};
+
+__device__ __forceinline__ bool cand_flag(const CandArgs &a, int cell, int &s, int &local) {
+    if (cell >= a.cell_begin[3]) return false;
+    s = cell >= a.cell_begin[2] ? 2 : (cell >= a.cell_begin[1] ? 1 : 0);
+    local = cell - a.cell_begin[s];
+    float obj = yh_sigmoid(a.pred[s][(size_t)local * (5 + a.nc) + 4]);
+    return obj > a.thr;
+}
+
+__global__ void cand_count_kernel(const CandArgs a) {
+    __shared__ int wsum[4];
+    int s, local;
+    bool f = cand_flag(a, blockIdx.x * 256 + threadIdx.x, s, local);
+    unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) a.blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void cand_scan_kernel(const CandArgs a) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < a.nblk; ++b) {
+            a.blk[a.nblk + b] = run;
+            run += a.blk[b];
+        }
+        a.count[0] = run;
+    }
+}
+
+__global__ void cand_write_kernel(const CandArgs a) {
+    __shared__ int wsum[4];
+    int s = 0, local = 0;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    bool f = cand_flag(a, cell, s, local);
+    unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    if (!f) return;
+    int pos = a.blk[a.nblk + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; ++k) pos += wsum[k];
+    if (pos >= a.cap) return;
+    const int ch = 5 + a.nc, G = a.grid[s];
+    const float *p = a.pred[s] + (size_t)local * ch;
+    int an = local % 3, q = local / 3;
+    int j = q % G, i = (q / G) % G;
+    // decode_predictions(pred, anchors, img_size) (train.py:758-774)
+    float bx = ((yh_sigmoid(p[0]) * 2.0f - 0.5f) + (float)j) / (float)G;
+    float by = ((yh_sigmoid(p[1]) * 2.0f - 0.5f) + (float)i) / (float)G;
+    float tw = 2.0f * yh_sigmoid(p[2]), th = 2.0f * yh_sigmoid(p[3]);
+    float bw = (a.anchors[(s * 3 + an) * 2 + 0] / a.img) * (tw * tw);
+    float bh = (a.anchors[(s * 3 + an) * 2 + 1] / a.img) * (th * th);
+    float obj = yh_sigmoid(p[4]);
+    float cp;
+    int cid = 0;
+    if (a.nc == 1) {
+        cp = yh_sigmoid(p[5]);
+    } else {
+        cp = -INFINITY;
+        for (int c = 0; c < a.nc; ++c) {
+            float v = yh_sigmoid(p[5 + c]);
+            if (v > cp) { cp = v; cid = c; }     // first maximum wins
+        }
+    }
+    // pixels -> corners -> un-letterbox (train.py:1192-1213), same operation order
+    float xc = bx * a.img, yc = by * a.img, wp = bw * a.img, hp = bh * a.img;
+    float x1 = xc - wp / 2, y1 = yc - hp / 2, x2 = xc + wp / 2, y2 = yc + hp / 2;
+    x1 = (x1 - a.pad_left) / a.scale; y1 = (y1 - a.pad_top) / a.scale;
+    x2 = (x2 - a.pad_left) / a.scale; y2 = (y2 - a.pad_top) / a.scale;
+    a.boxes[4 * pos + 0] = x1; a.boxes[4 * pos + 1] = y1; a.boxes[4 * pos + 2] = x2; a.boxes[4 * pos + 3] = y2;
+    a.scores[pos] = obj * cp;
+    a.classes[pos] = cid;
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kSortLds = 16384;   // keys that fit the 128 KiB LDS sort buffer
+constexpr int kNmsThreads = 1024;
+
+__device__ __forceinline__ uint64_t make_key(float score, int idx) {
+    uint32_t u = __float_as_uint(score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
+    return ((uint64_t)(~u) << 32) | (uint32_t)idx;    // ascending key = descending score, then index
+}
+
+__device__ void bitonic_sort(uint64_t *k, int n) {   // n is a power of two; whole workgroup
+    for (int size = 2; size <= n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+                int lo = 2 * i - (i & (stride - 1));
+                int hi = lo + stride;
+                bool up = (lo & size) == 0;
+                uint64_t a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    __syncthreads();
+}
+
+struct NmsArgs {
+    const float *boxes, *scores;
+    const int32_t *classes, *count;
+    int cap, W;                 // W = words per mask row = ceil(cap/64)
+    float thr;
+    uint64_t *keys;             // [pow2(cap)]
+    float *sboxes;              // [cap][4]
+    int32_t *sclasses, *order;  // [cap]
+    uint64_t *mask;             // [cap][W]
+    int32_t *keep, *nkeep;
+};
+
+__global__ __launch_bounds__(kNmsThreads) void nms_sort_kernel(const NmsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lkeys[];
+    int M = a.count[0];
+    if (M > a.cap) M = a.cap;
+    int n = 1;
+    while (n < M) n <<= 1;
+    uint64_t *k = n <= kSortLds ? lkeys : a.keys;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) k[i] = i < M ? make_key(a.scores[i], i) : ~0ull;
+    if (n > 1) bitonic_sort(k, n);
+    __syncthreads();
+    for (int r = threadIdx.x; r < M; r += blockDim.x) {
+        int idx = (int)(uint32_t)k[r];
+        a.order[r] = idx;
+        a.sclasses[r] = a.classes[idx];
+        *(f32x4 *)(a.sboxes + 4 * r) = *(const f32x4 *)(a.boxes + 4 * idx);
+    }
+}
+
+__global__ void nms_mask_kernel(const NmsArgs a) {
+    int M = a.count[0];
+    if (M > a.cap) M = a.cap;
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || rb * 64 >= M || cb * 64 >= M) return;
+    __shared__ float cbx[64][4];
+    __shared__ int ccl[64];
+    const int t = threadIdx.x, cj = cb * 64 + t;
+    if (cj < M) {
+        *(f32x4 *)cbx[t] = *(const f32x4 *)(a.sboxes + 4 * cj);
+        ccl[t] = a.sclasses[cj];
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= M) return;
+    f32x4 bi = *(const f32x4 *)(a.sboxes + 4 * i);
+    const int ci = a.sclasses[i];
+    const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+    uint64_t bits = 0;
+    int ncol = M - cb * 64;
+    if (ncol > 64) ncol = 64;
+    for (int c = (rb == cb ? t + 1 : 0); c < ncol; ++c) {
+        if (ccl[c] != ci) continue;
+        float xx1 = fmaxf(bi[0], cbx[c][0]), yy1 = fmaxf(bi[1], cbx[c][1]);
+        float xx2 = fminf(bi[2], cbx[c][2]), yy2 = fminf(bi[3], cbx[c][3]);
+        float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+        float inter = w * h;
+        float aj = (cbx[c][2] - cbx[c][0]) * (cbx[c][3] - cbx[c][1]);
+        float iou = inter / ((ai + aj) - inter);
+        if (iou > a.thr) bits |= 1ull << c;
+    }
+    a.mask[(size_t)i * a.W + cb] = bits;
+}
+
+__global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) {
+    __shared__ uint64_t cur_word, kept_word;
+    __shared__ int nk_sh;
+    int M = a.count[0];
+    if (M > a.cap) M = a.cap;
+    const int nw = (M + 63) >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    // each thread owns removal words t, t+1024, ... (at most cap/64/1024 of them: keep 4)
+    uint64_t remv[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int w = t + q * kNmsThreads;
+        if (w == nw - 1 && (M & 63)) remv[q] = ~0ull << (M & 63);   // boxes past M never win
+    }
+    if (t == 0) nk_sh = 0;
+    __syncthreads();
+    for (int bi = 0; bi < nw; ++bi) {
+        const int owner = bi % kNmsThreads, slot = bi / kNmsThreads;
+        if (t == owner) {
+            uint64_t v = slot == 0 ? remv[0] : (slot == 1 ? remv[1] : (slot == 2 ? remv[2] : remv[3]));
+            cur_word = v;
+        }
+        __syncthreads();
+        if (t < 64) {   // wave 0 resolves the block against its own diagonal word
+            const int row = bi * 64 + lane;
+            uint64_t diag = row < M ? a.mask[(size_t)row * a.W + bi] : 0ull;
+            uint64_t cur = cur_word, kept = 0;
+            for (int b = 0; b < 64; ++b) {
+                uint64_t d = __shfl(diag, b);
+                if (!((cur >> b) & 1ull)) { kept |= 1ull << b; cur |= d; }
+            }
+            int base = nk_sh;
+            if ((kept >> lane) & 1ull) a.keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = a.order[row];
+            if (lane == 0) { kept_word = kept; nk_sh = base + __popcll(kept); }
+        }
+        __syncthreads();
+        const uint64_t kept = kept_word;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int w = t + q * kNmsThreads;
+            if (w > bi && w < nw) {
+                uint64_t acc = remv[q], kk = kept;
+                while (kk) {
+                    int b = __ffsll((long long)kk) - 1;
+                    kk &= kk - 1;
+                    acc |= a.mask[(size_t)(bi * 64 + b) * a.W + w];
+                }
+                remv[q] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) a.nkeep[0] = nk_sh;
+}
+
+inline int pow2_ge(int v) { int n = 1; while (n < v) n <<= 1; return n; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" int64_t yh_candidates_ws(const int grid[3]) {
+    int64_t cells = 0;
+    for (int s = 0; s < 3; ++s) cells += (int64_t)grid[s] * grid[s] * 3;
+    return 2 * cdiv64(cells, 256);
+}
+
+extern "C" int yh_candidates(const float *const pred[3], const float *anchors, const int grid[3], int nc, float img_size,
+                             float conf_thr, float pad_left, float pad_top, float scale, float *boxes, float *scores,
+                             int32_t *classes, int32_t *count, int cap, int32_t *ws, void *stream) {
+    YH_REQUIRE(pred && anchors && grid && boxes && scores && classes && count && ws && cap > 0 && nc >= 1,
+               "candidates: bad argument");
+    YH_REQUIRE(((uintptr_t)boxes & 15) == 0, "candidates: boxes must be 16-byte aligned");
+    CandArgs a{};
+    int cells = 0;
+    for (int s = 0; s < 3; ++s) {
+        YH_REQUIRE(pred[s] && grid[s] > 0, "candidates: scale %d missing", s);
+        a.pred[s] = pred[s]; a.grid[s] = grid[s];
+        a.cell_begin[s] = cells;
+        cells += grid[s] * grid[s] * 3;
+    }
+    a.cell_begin[3] = cells;
+    for (int k = 0; k < 18; ++k) a.anchors[k] = anchors[k];
+    a.nc = nc; a.cap = cap; a.img = img_size; a.thr = conf_thr;
+    a.pad_left = pad_left; a.pad_top = pad_top; a.scale = scale;
+    a.boxes = boxes; a.scores = scores; a.classes = classes; a.count = count; a.blk = ws;
+    a.nblk = cdiv(cells, 256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cand_count_kernel, dim3(a.nblk), dim3(256), 0, st, a);
+    YH_CHECK_LAUNCH("cand_count");
+    hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(64), 0, st, a);
+    YH_CHECK_LAUNCH("cand_scan");
+    hipLaunchKernelGGL(cand_write_kernel, dim3(a.nblk), dim3(256), 0, st, a);
+    YH_CHECK_LAUNCH("cand_write");
+    return 0;
+}
+
+extern "C" int64_t yh_nms_ws(int cap) {
+    if (cap <= 0) return 0;
+    size_t W = (size_t)(cap + 63) / 64;
+    size_t b = align_up((size_t)pow2_ge(cap) * 8, 256);   // keys
+    b += align_up((size_t)cap * 16, 256);                 // sorted boxes
+    b += 2 * align_up((size_t)cap * 4, 256);              // sorted classes, order
+    b += align_up((size_t)cap * W * 8, 256);              // suppression bit matrix
+    return (int64_t)b;
+}
+
+extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count, int cap,
+                      float iou_thr, int32_t *keep, int32_t *nkeep, void *ws, void *stream) {
+    YH_REQUIRE(boxes && scores && classes && count && keep && nkeep && ws && cap > 0, "nms: bad argument");
+    YH_REQUIRE(cap <= 64 * 4 * kNmsThreads, "nms: capacity %d above the supported %d", cap, 64 * 4 * kNmsThreads);
+    YH_REQUIRE(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)ws & 255) == 0, "nms: boxes 16-byte / workspace 256-byte alignment");
+    NmsArgs a{};
+    a.boxes = boxes; a.scores = scores; a.classes = classes; a.count = count;
+    a.cap = cap; a.W = (cap + 63) / 64; a.thr = iou_thr; a.keep = keep; a.nkeep = nkeep;
+    char *p = (char *)ws;
+    a.keys = (uint64_t *)p;   p += align_up((size_t)pow2_ge(cap) * 8, 256);
+    a.sboxes = (float *)p;    p += align_up((size_t)cap * 16, 256);
+    a.sclasses = (int32_t *)p; p += align_up((size_t)cap * 4, 256);
+    a.order = (int32_t *)p;   p += align_up((size_t)cap * 4, 256);
+    a.mask = (uint64_t *)p;
+    hipStream_t st = (hipStream_t)stream;
+    int n = pow2_ge(cap);
+    size_t lds = (size_t)(n < kSortLds ? n : kSortLds) * 8;
+    static size_t attr = 0;
+    if (lds > attr) {
+        YH_HIP(hipFuncSetAttribute((const void *)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(kNmsThreads), lds, st, a);
+    YH_CHECK_LAUNCH("nms_sort");
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(a.W, a.W), dim3(64), 0, st, a);
+    YH_CHECK_LAUNCH("nms_mask");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kNmsThreads), 0, st, a);
+    YH_CHECK_LAUNCH("nms_scan");
+    return 0;
+}

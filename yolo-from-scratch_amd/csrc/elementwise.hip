@@ -1,0 +1,496 @@
+// HBM-bound kernels of the hot path: layout changes, weight packing, BatchNorm(+SiLU) forward and
+// backward, SPPF max-pool, column sums.  All are float4-vectorised over the channel axis (NHWC, so
+// the channel axis is the contiguous one) and use grid-stride loops capped at a few thousand
+// workgroups; every cross-workgroup reduction is two-stage with a fixed summation order, so results
+// are bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int ld,
+                                    int cpad, int64_t npix) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = p / HW, hw = p - b * HW;
+        const float *s = src + b * C * (int64_t)HW + hw;
+        float *d = dst + p * ld;
+        for (int c = 0; c < cpad; ++c) d[c] = c < C ? s[(int64_t)c * HW] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int ld,
+                                    int accumulate, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t hw = i % HW, q = i / HW;
+        int c = (int)(q % C);
+        int64_t b = q / C;
+        float v = src[(b * HW + hw) * ld + c];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+
+__global__ void pack_weights_kernel(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb,
+                                    int Cout, int Cin, int kk, int cin_pad, int ldwf, int ldwb) {
+    const int nf = wf ? kk * cin_pad * ldwf : 0;
+    const int nb = wb ? kk * Cout * ldwb : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+        if (i < nf) {
+            int n = i % ldwf, q = i / ldwf;
+            int ci = q % cin_pad, t = q / cin_pad;
+            wf[i] = (n < Cout && ci < Cin) ? w[((size_t)n * Cin + ci) * kk + t] : 0.f;
+        } else {
+            int j = i - nf;
+            int ci = j % ldwb, q = j / ldwb;
+            int co = q % Cout, t = q / Cout;
+            wb[j] = (ci < Cin) ? w[((size_t)co * Cin + ci) * kk + t] : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums: stage 1 -> partial[blk][C], stage 2 -> out[C]
+__global__ void colsum_stage1(const float *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
+                              int64_t rows_per_blk) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    int cw = 1;
+    while (cw < C && cw < 256) cw <<= 1;
+    const int rg = 256 / cw, c_in = t % cw, r_in = t / cw;
+    int64_t r0 = blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk;
+    if (r1 > M) r1 = M;
+    for (int cb = 0; cb < C; cb += cw) {
+        int c = cb + c_in;
+        float s = 0.f;
+        if (c < C)
+            for (int64_t r = r0 + r_in; r < r1; r += rg) s += x[r * ldx + c];
+        red[t] = s;
+        __syncthreads();
+        if (r_in == 0 && c < C) {
+            float tot = 0.f;
+            for (int k = 0; k < rg; ++k) tot += red[k * cw + c_in];
+            part[(size_t)blockIdx.x * C + c] = tot;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_stage2(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * C + c];
+    out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics: one workgroup per channel reduces the conv epilogue's partials in double.
+__global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, double count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
+                                   float *__restrict__ coef, int C) {
+    __shared__ double rs[4], rq[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = t; b < nblk; b += blockDim.x) {
+        s += (double)part[((size_t)b * 2 + 0) * C + c];
+        q += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((t & 63) == 0) { rs[t >> 6] = s; rq[t >> 6] = q; }
+    __syncthreads();
+    if (t == 0) {
+        double S = rs[0] + rs[1] + rs[2] + rs[3], Q = rq[0] + rq[1] + rq[2] + rq[3];
+        double mean = S / count, var = Q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        float scale = gamma[c] * invstd;
+        coef[c] = scale;
+        coef[C + c] = beta[c] - (float)mean * scale;
+        coef[2 * C + c] = (float)mean;
+        coef[3 * C + c] = invstd;
+        if (rmean) {
+            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_coef_kernel(const float *gamma, const float *beta, const float *rmean, const float *rvar,
+                                    float eps, float *coef, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.0f / sqrtf(rvar[c] + eps);
+    float scale = gamma[c] * invstd;
+    coef[c] = scale;
+    coef[C + c] = beta[c] - rmean[c] * scale;
+    coef[2 * C + c] = rmean[c];
+    coef[3 * C + c] = invstd;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z * yh_sigmoid(z); }
+__device__ __forceinline__ float silu_grad(float z) {
+    float s = yh_sigmoid(z);
+    return s * (1.f + z * (1.f - s));
+}
+
+// a = silu(y*scale+shift) (+res); float4 over channels
+__global__ void bn_silu_fwd_kernel(const float *__restrict__ y, int ldy, const float *__restrict__ coef,
+                                   const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
+                                   int64_t M, int C, int H, int W, int upsample) {
+    const int cq = C >> 2;
+    const int64_t total = M * cq;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / cq;
+        int c = (int)(i - m * cq) << 2;
+        f32x4 v = *(const f32x4 *)(y + m * ldy + c);
+        f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
+        f32x4 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = silu_f(v[e] * sc[e] + sh[e]);
+        if (res) {
+            f32x4 r = *(const f32x4 *)(res + m * ldr + c);
+            a += r;
+        }
+        if (!upsample) {
+            *(f32x4 *)(out + m * ldo + c) = a;
+        } else {
+            int64_t w = m % W, q = m / W;
+            int64_t h = q % H, b = q / H;
+            float *o = out + (((b * 2 * H + 2 * h) * 2 * W) + 2 * w) * ldo + c;
+            *(f32x4 *)(o) = a;
+            *(f32x4 *)(o + ldo) = a;
+            *(f32x4 *)(o + (size_t)2 * W * ldo) = a;
+            *(f32x4 *)(o + (size_t)2 * W * ldo + ldo) = a;
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 load_da(const float *__restrict__ da, int ldda, int64_t m, int c, int H, int W,
+                                         int upsample) {
+    if (!upsample) return *(const f32x4 *)(da + m * ldda + c);
+    int64_t w = m % W, q = m / W;
+    int64_t h = q % H, b = q / H;
+    const float *p = da + (((b * 2 * H + 2 * h) * 2 * W) + 2 * w) * ldda + c;
+    f32x4 a = *(const f32x4 *)p, b1 = *(const f32x4 *)(p + ldda);
+    f32x4 c1 = *(const f32x4 *)(p + (size_t)2 * W * ldda), d1 = *(const f32x4 *)(p + (size_t)2 * W * ldda + ldda);
+    return (a + b1) + (c1 + d1);
+}
+
+// stage 1 of the backward: per-workgroup partial sums of dz and dz*xhat (per channel)
+__global__ void bn_silu_bwd_reduce_kernel(const float *__restrict__ da, int ldda, const float *__restrict__ y,
+                                          int ldy, const float *__restrict__ coef, float *__restrict__ part,
+                                          int64_t M, int C, int H, int W, int upsample, int64_t rows_per_blk) {
+    extern __shared__ float red[];   // [256][8]
+    const int t = threadIdx.x, cq = C >> 2;
+    const int rg = 256 / cq;          // row groups (cq <= 64 -> rg >= 4); for cq > 256 not supported
+    const int c4 = t % cq, r_in = t / cq;
+    int64_t r0 = blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk;
+    if (r1 > M) r1 = M;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (r_in < rg) {
+        const int c = c4 << 2;
+        f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
+        f32x4 mu = *(const f32x4 *)(coef + 2 * C + c), is = *(const f32x4 *)(coef + 3 * C + c);
+        for (int64_t m = r0 + r_in; m < r1; m += rg) {
+            f32x4 yv = *(const f32x4 *)(y + m * ldy + c);
+            f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dz = g[e] * silu_grad(yv[e] * sc[e] + sh[e]);
+                s1[e] += dz;
+                s2[e] += dz * ((yv[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[t * 8 + e] = s1[e]; red[t * 8 + 4 + e] = s2[e]; }
+    __syncthreads();
+    if (t < cq) {
+        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        for (int k = 0; k < rg; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += red[(k * cq + t) * 8 + e]; b[e] += red[(k * cq + t) * 8 + 4 + e]; }
+        *(f32x4 *)(part + ((size_t)blockIdx.x * 2 + 0) * C + 4 * t) = a;
+        *(f32x4 *)(part + ((size_t)blockIdx.x * 2 + 1) * C + 4 * t) = b;
+    }
+}
+
+// totals of the partials -> dbeta (sum dz) and dgamma (sum dz*xhat); one workgroup per channel
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, int C) {
+    __shared__ double rs[4], rq[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = t; b < nblk; b += blockDim.x) {
+        s += (double)part[((size_t)b * 2 + 0) * C + c];
+        q += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((t & 63) == 0) { rs[t >> 6] = s; rq[t >> 6] = q; }
+    __syncthreads();
+    if (t == 0) {
+        dbeta[c] = (float)(rs[0] + rs[1] + rs[2] + rs[3]);
+        dgamma[c] = (float)(rq[0] + rq[1] + rq[2] + rq[3]);
+    }
+}
+
+__global__ void bn_silu_bwd_apply_kernel(const float *__restrict__ da, int ldda, const float *__restrict__ y,
+                                         int ldy, const float *__restrict__ coef, const float *__restrict__ dgamma,
+                                         const float *__restrict__ dbeta, float *__restrict__ dy, int lddy,
+                                         float *__restrict__ dres, int lddres, int res_acc, int64_t M, int C, int H,
+                                         int W, int upsample) {
+    const int cq = C >> 2;
+    const int64_t total = M * cq;
+    const float inv_n = 1.0f / (float)M;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / cq;
+        int c = (int)(i - m * cq) << 2;
+        f32x4 yv = *(const f32x4 *)(y + m * ldy + c);
+        f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
+        f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
+        f32x4 mu = *(const f32x4 *)(coef + 2 * C + c), is = *(const f32x4 *)(coef + 3 * C + c);
+        f32x4 dg = *(const f32x4 *)(dgamma + c), db = *(const f32x4 *)(dbeta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float dz = g[e] * silu_grad(yv[e] * sc[e] + sh[e]);
+            float xh = (yv[e] - mu[e]) * is[e];
+            o[e] = sc[e] * (dz - db[e] * inv_n - xh * dg[e] * inv_n);
+        }
+        *(f32x4 *)(dy + m * lddy + c) = o;
+        if (dres) {
+            float *r = dres + m * lddres + c;
+            if (res_acc) g += *(const f32x4 *)r;
+            *(f32x4 *)r = g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void maxpool5_fwd_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy,
+                                    uint8_t *__restrict__ arg, int H, int W, int C, int64_t total) {
+    const int cq = C >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / cq;
+        int c = (int)(i - m * cq) << 2;
+        int w = (int)(m % W);
+        int64_t q = m / W;
+        int h = (int)(q % H);
+        int64_t b = q / H;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int kh = 0; kh < 5; ++kh) {
+            int ih = h + kh - 2;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 5; ++kw) {
+                int iw = w + kw - 2;
+                if (iw < 0 || iw >= W) continue;
+                f32x4 v = *(const f32x4 *)(x + ((b * H + ih) * W + iw) * ldx + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 5 + kw; }
+                first = false;
+            }
+        }
+        *(f32x4 *)(y + m * ldy + c) = best;
+        uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        *(uint32_t *)(arg + m * C + c) = packed;
+    }
+}
+
+__global__ void maxpool5_bwd_kernel(const float *__restrict__ dy, int lddy, const uint8_t *__restrict__ arg,
+                                    float *__restrict__ dx, int lddx, int H, int W, int C, int64_t total) {
+    const int cq = C >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / cq;
+        int c = (int)(i - m * cq) << 2;
+        int w = (int)(m % W);
+        int64_t q = m / W;
+        int h = (int)(q % H);
+        int64_t b = q / H;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int kh = 0; kh < 5; ++kh) {
+            int oh = h - kh + 2;
+            if (oh < 0 || oh >= H) continue;
+            for (int kw = 0; kw < 5; ++kw) {
+                int ow = w - kw + 2;
+                if (ow < 0 || ow >= W) continue;
+                int64_t om = (b * H + oh) * W + ow;
+                uint32_t packed = *(const uint32_t *)(arg + om * C + c);
+                f32x4 g = *(const f32x4 *)(dy + om * lddy + c);
+                uint32_t want = (uint32_t)(kh * 5 + kw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((packed >> (8 * e)) & 0xffu) == want) acc[e] += g[e];
+            }
+        }
+        float *d = dx + m * lddx + c;
+        *(f32x4 *)d = *(const f32x4 *)d + acc;
+    }
+}
+
+__global__ void add_int64_kernel(int64_t *p, int64_t v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p += v;
+}
+
+inline int grid_for(int64_t work_items, int threads = 256) {
+    int64_t g = cdiv64(work_items, threads);
+    return (int)(g < 1 ? 1 : (g > kMaxBlocks ? kMaxBlocks : g));
+}
+
+}  // namespace
+
+extern "C" int yh_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, int ld, int cpad,
+                               void *stream) {
+    YH_REQUIRE(src && dst && B > 0 && C > 0 && cpad >= C && ld >= cpad, "nchw_to_nhwc: bad argument");
+    int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       H * W, ld, cpad, npix);
+    YH_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, int ld, int accumulate,
+                               void *stream) {
+    YH_REQUIRE(src && dst && B > 0 && C > 0 && ld >= C, "nhwc_to_nchw: bad argument");
+    int64_t total = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       H * W, ld, accumulate, total);
+    YH_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int yh_pack_weights(const float *oihw, float *wf, float *wb, int Cout, int Cin, int k, int cin_pad,
+                               int ldwf, int ldwb, void *stream) {
+    YH_REQUIRE(oihw && (wf || wb) && cin_pad >= Cin, "pack_weights: bad argument");
+    YH_REQUIRE(!wf || (ldwf >= Cout && ldwf % 4 == 0), "pack_weights: ldwf=%d must be >= Cout and a multiple of 4", ldwf);
+    YH_REQUIRE(!wb || (ldwb >= Cin && ldwb % 4 == 0), "pack_weights: ldwb=%d must be >= Cin and a multiple of 4", ldwb);
+    int64_t n = (wf ? (int64_t)k * k * cin_pad * ldwf : 0) + (wb ? (int64_t)k * k * Cout * ldwb : 0);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, oihw, wf, wb, Cout,
+                       Cin, k * k, cin_pad, ldwf, ldwb);
+    YH_CHECK_LAUNCH("pack_weights");
+    return 0;
+}
+
+static int colsum_blocks(int64_t M) {
+    int64_t b = cdiv64(M, 512);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+extern "C" int64_t yh_colsum_ws(int64_t M, int C) { return (int64_t)colsum_blocks(M) * C; }
+extern "C" int yh_colsum(const float *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream) {
+    YH_REQUIRE(x && out && ws && M > 0 && C > 0 && ldx >= C, "colsum: bad argument");
+    int nblk = colsum_blocks(M);
+    int64_t rows = cdiv64(M, nblk);
+    hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
+    YH_CHECK_LAUNCH("colsum_stage1");
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out);
+    YH_CHECK_LAUNCH("colsum_stage2");
+    return 0;
+}
+
+extern "C" int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
+                              float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
+                              void *stream) {
+    YH_REQUIRE(partials && gamma && beta && coef && nblk > 0 && count > 0 && C > 0, "bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, (double)count,
+                       gamma, beta, running_mean, running_var, momentum, eps, coef, C);
+    YH_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean,
+                               const float *running_var, float eps, float *coef, int C, void *stream) {
+    YH_REQUIRE(gamma && beta && running_mean && running_var && coef && C > 0, "bn_eval_coef: bad argument");
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, coef, C);
+    YH_CHECK_LAUNCH("bn_eval_coef");
+    return 0;
+}
+
+#define YH_REQ_VEC4(name, C, ...)                                                                     \
+    YH_REQUIRE((C) % 4 == 0 && (C) <= 1024, name ": C=%d must be a multiple of 4 (<= 1024)", (C));       \
+    do {                                                                                              \
+        const int lds__[] = {__VA_ARGS__};                                                            \
+        for (int ld__ : lds__) YH_REQUIRE(ld__ % 4 == 0, name ": ld=%d must be a multiple of 4", ld__); \
+    } while (0)
+
+extern "C" int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
+                              int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    YH_REQUIRE(y && coef && out && M > 0, "bn_silu_fwd: bad argument");
+    YH_REQ_VEC4("bn_silu_fwd", C, ldy, ldo, residual ? ldr : 0);
+    YH_REQUIRE(!upsample || (H > 0 && W > 0 && M % ((int64_t)H * W) == 0), "bn_silu_fwd: upsample needs H, W");
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
+                       residual, ldr, out, ldo, M, C, H, W, upsample);
+    YH_CHECK_LAUNCH("bn_silu_fwd");
+    return 0;
+}
+
+extern "C" int yh_bn_bwd_blocks(int64_t M, int C) {
+    int rg = 256 / (C / 4 > 0 ? C / 4 : 1);
+    if (rg < 1) rg = 1;
+    int64_t b = cdiv64(M, (int64_t)rg * 16);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef,
+                                     float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    YH_REQUIRE(da && y && coef && partials && M > 0, "bn_silu_bwd_reduce: bad argument");
+    YH_REQ_VEC4("bn_silu_bwd_reduce", C, ldda, ldy);
+    YH_REQUIRE(C <= 1024, "bn_silu_bwd_reduce: C too large");
+    int nblk = yh_bn_bwd_blocks(M, C);
+    int64_t rows = cdiv64(M, nblk);
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
+                       da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
+    YH_CHECK_LAUNCH("bn_silu_bwd_reduce");
+    return 0;
+}
+
+extern "C" int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, int ldy, const float *coef,
+                                    const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
+                                    float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C,
+                                    int H, int W, int upsample, void *stream) {
+    (void)gamma;
+    YH_REQUIRE(da && y && coef && partials && dgamma && dbeta && dy && M > 0 && nblk > 0, "bn_silu_bwd_apply: bad argument");
+    YH_REQ_VEC4("bn_silu_bwd_apply", C, ldda, ldy, lddy, dres ? lddres : 0);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
+                       C);
+    YH_CHECK_LAUNCH("bn_bwd_finalize");
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,
+                       y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
+    YH_CHECK_LAUNCH("bn_silu_bwd_apply");
+    return 0;
+}
+
+extern "C" int yh_maxpool5_fwd(const float *x, int ldx, float *y, int ldy, uint8_t *argmax, int B, int H, int W, int C,
+                               void *stream) {
+    YH_REQUIRE(x && y && argmax && B > 0 && H > 0 && W > 0, "maxpool5_fwd: bad argument");
+    YH_REQ_VEC4("maxpool5_fwd", C, ldx, ldy);
+    int64_t total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                       argmax, H, W, C, total);
+    YH_CHECK_LAUNCH("maxpool5_fwd");
+    return 0;
+}
+
+extern "C" int yh_maxpool5_bwd(const float *dy, int lddy, const uint8_t *argmax, float *dx, int lddx, int B, int H,
+                               int W, int C, void *stream) {
+    YH_REQUIRE(dy && dx && argmax && B > 0 && H > 0 && W > 0, "maxpool5_bwd: bad argument");
+    YH_REQ_VEC4("maxpool5_bwd", C, lddy, lddx);
+    int64_t total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, argmax,
+                       dx, lddx, H, W, C, total);
+    YH_CHECK_LAUNCH("maxpool5_bwd");
+    return 0;
+}
+
+extern "C" int yh_add_int64(int64_t *p, int64_t v, void *stream) {
+    YH_REQUIRE(p, "add_int64: null pointer");
+    hipLaunchKernelGGL(add_int64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);
+    YH_CHECK_LAUNCH("add_int64");
+    return 0;
+}

@@ -1,0 +1,381 @@
+// Fused multi-scale YOLO loss (decode + CIoU + BCE-with-logits), forward and backward in one pass
+// over the three head outputs, plus the standalone decode / CIoU entry points.
+//
+// Latency-bound scan work, not MFMA work: one thread per (image, row, col, anchor) cell.  The three
+// scales are processed by one launch; every workgroup belongs to exactly one scale so its partial
+// sums (fp64) are per scale.  Sums over workgroups are added in index order by a final one-workgroup
+// kernel: no float atomics, bitwise reproducible.  The number of positives per scale (the mean's
+// denominator, needed by the gradient) comes from an integer-atomic counting pre-pass.
+//
+// CIoU's gradient is obtained with forward-mode dual numbers over the four decoded box coordinates;
+// tie conventions follow torch's autograd (min/max split the gradient evenly on ties, clamp passes
+// the gradient at the boundary).
+#include "common.h"
+
+namespace {
+
+struct D4 {
+    float v, d[4];
+};
+__device__ __forceinline__ D4 d4_const(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 d4_var(float x, int i) {
+    D4 r = d4_const(x);
+    r.d[i] = 1.f;
+    return r;
+}
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) {
+    D4 r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) {
+    D4 r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) {
+    D4 r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+    D4 r; r.v = a.v / b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+    return r;
+}
+__device__ __forceinline__ D4 d4_scale(D4 a, float s) {
+    D4 r; r.v = a.v * s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * s;
+    return r;
+}
+__device__ __forceinline__ D4 d4_addc(D4 a, float c) { a.v += c; return a; }
+// min / max against a constant (the target box is constant)
+__device__ __forceinline__ D4 d4_minc(D4 a, float c) {
+    if (a.v < c) return a;
+    if (a.v > c) return d4_const(c);
+    return D4{c, {0.5f * a.d[0], 0.5f * a.d[1], 0.5f * a.d[2], 0.5f * a.d[3]}};
+}
+__device__ __forceinline__ D4 d4_maxc(D4 a, float c) {
+    if (a.v > c) return a;
+    if (a.v < c) return d4_const(c);
+    return D4{c, {0.5f * a.d[0], 0.5f * a.d[1], 0.5f * a.d[2], 0.5f * a.d[3]}};
+}
+__device__ __forceinline__ D4 d4_clamp0(D4 a) { return a.v >= 0.f ? a : d4_const(0.f); }
+__device__ __forceinline__ D4 d4_sq(D4 a) {
+    D4 r; r.v = a.v * a.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = 2.f * a.v * a.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 d4_atan(D4 a) {
+    D4 r; r.v = atanf(a.v);
+    float g = 1.f / (1.f + a.v * a.v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = g * a.d[i];
+    return r;
+}
+
+// 1 - CIoU of one (pred, target) pair and its gradient w.r.t. (px, py, pw, ph); train.py:646-708.
+__device__ __forceinline__ float ciou_term(const float p[4], const float t[4], float eps, float grad[4]) {
+    D4 px = d4_var(p[0], 0), py = d4_var(p[1], 1), pw = d4_var(p[2], 2), ph = d4_var(p[3], 3);
+    const float tx = t[0], ty = t[1], tw = t[2], th = t[3];
+    D4 hw = d4_scale(pw, 0.5f), hh = d4_scale(ph, 0.5f);        // pw / 2
+    D4 px1 = px - hw, px2 = px + hw, py1 = py - hh, py2 = py + hh;
+    float tx1 = tx - tw / 2, tx2 = tx + tw / 2, ty1 = ty - th / 2, ty2 = ty + th / 2;
+    D4 iw = d4_clamp0(d4_minc(px2, tx2) - d4_maxc(px1, tx1));
+    D4 ih = d4_clamp0(d4_minc(py2, ty2) - d4_maxc(py1, ty1));
+    D4 inter = iw * ih;
+    D4 uni = d4_addc(pw * ph, tw * th) - inter;
+    D4 iou = inter / d4_addc(uni, eps);
+    D4 rho2 = d4_sq(d4_addc(px, -tx)) + d4_sq(d4_addc(py, -ty));
+    D4 cw = d4_maxc(px2, tx2) - d4_minc(px1, tx1);
+    D4 ch = d4_maxc(py2, ty2) - d4_minc(py1, ty1);
+    D4 c2 = d4_addc(d4_sq(cw) + d4_sq(ch), eps);
+    D4 dist = rho2 / c2;
+    float at_t = atanf(tw / (th + eps));
+    D4 dat = d4_addc(d4_atan(pw / d4_addc(ph, eps)), -at_t);
+    const float k = (float)(4.0 / (3.14159265358979323846 * 3.14159265358979323846));
+    D4 v = d4_scale(d4_sq(dat), k);
+    float alpha = v.v / (1.f - iou.v + v.v + eps);              // constant w.r.t. the gradient (no_grad)
+    D4 ciou = iou - dist - d4_scale(v, alpha);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) grad[i] = -ciou.d[i];
+    return 1.f - ciou.v;
+}
+
+__device__ __forceinline__ float bce_logits(float x, float z) {
+    return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+}
+
+struct LossArgs {
+    const float *pred[3], *tgt[3];
+    float *dpred[3];
+    float anchors[18];
+    int grid[3];
+    int64_t cells[3];       // B*G*G*3 per scale
+    int blk_begin[4];       // workgroup ranges per scale
+    int B, nc;
+    float img, gscale;
+    int *counts;            // [4]
+    double *part;           // [nblk][3]
+    float *out;             // [13]
+};
+
+__global__ void loss_count_kernel(const LossArgs a) {
+    int s = blockIdx.x >= a.blk_begin[2] ? 2 : (blockIdx.x >= a.blk_begin[1] ? 1 : 0);
+    int64_t cell = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256 + threadIdx.x;
+    const int ch = 5 + a.nc;
+    bool pos = cell < a.cells[s] && a.tgt[s][cell * ch + 4] > 0.5f;
+    unsigned long long m = __ballot(pos);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counts[s], __popcll(m));
+}
+
+__global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
+    __shared__ double red[4][3];
+    const int s = blockIdx.x >= a.blk_begin[2] ? 2 : (blockIdx.x >= a.blk_begin[1] ? 1 : 0);
+    const int64_t cell = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256 + threadIdx.x;
+    const int ch = 5 + a.nc, G = a.grid[s];
+    const float wobj = s == 0 ? 4.0f : (s == 1 ? 1.0f : 0.4f);
+    const int npos = a.counts[s];
+    double lbox = 0.0, lobj = 0.0, lcls = 0.0;
+    if (cell < a.cells[s]) {
+        const float *p = a.pred[s] + cell * ch;
+        const float *t = a.tgt[s] + cell * ch;
+        float *d = a.dpred[s] ? a.dpred[s] + cell * ch : nullptr;
+        const float x = p[4], z = t[4];
+        lobj = (double)bce_logits(x, z);
+        if (d) d[4] = (yh_sigmoid(x) - z) * (wobj / (float)a.cells[s]) * a.gscale;
+        if (z > 0.5f) {
+            int an = (int)(cell % 3);
+            int64_t q = cell / 3;
+            int j = (int)(q % G);
+            int i = (int)((q / G) % G);
+            float sg[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sg[e] = yh_sigmoid(p[e]);
+            float aw = a.anchors[(s * 3 + an) * 2 + 0] / a.img, ah = a.anchors[(s * 3 + an) * 2 + 1] / a.img;
+            float box[4], tb[4] = {t[0], t[1], t[2], t[3]}, gb[4];
+            box[0] = ((sg[0] * 2.0f - 0.5f) + (float)j) / (float)G;
+            box[1] = ((sg[1] * 2.0f - 0.5f) + (float)i) / (float)G;
+            float two_w = 2.0f * sg[2], two_h = 2.0f * sg[3];
+            box[2] = aw * (two_w * two_w);
+            box[3] = ah * (two_h * two_h);
+            lbox = (double)ciou_term(box, tb, 1e-7f, gb);
+            if (d) {
+                float kb = 0.05f / (float)npos * a.gscale;
+                d[0] = gb[0] * (2.0f * sg[0] * (1.f - sg[0]) / (float)G) * kb;
+                d[1] = gb[1] * (2.0f * sg[1] * (1.f - sg[1]) / (float)G) * kb;
+                d[2] = gb[2] * (aw * 8.0f * sg[2] * sg[2] * (1.f - sg[2])) * kb;
+                d[3] = gb[3] * (ah * 8.0f * sg[3] * sg[3] * (1.f - sg[3])) * kb;
+            }
+            float kc = a.nc > 0 ? 0.5f / ((float)npos * (float)a.nc) * a.gscale : 0.f;
+            for (int c = 0; c < a.nc; ++c) {
+                float xc = p[5 + c], zc = t[5 + c];
+                lcls += (double)bce_logits(xc, zc);
+                if (d) d[5 + c] = (yh_sigmoid(xc) - zc) * kc;
+            }
+        }
+    }
+    lbox = wave_sum_d(lbox); lobj = wave_sum_d(lobj); lcls = wave_sum_d(lcls);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = lbox; red[w][1] = lobj; red[w][2] = lcls; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        a.part[(size_t)blockIdx.x * 3 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void loss_final_kernel(const LossArgs a) {
+    __shared__ double sh[3][3][4];
+    const int t = threadIdx.x, w = t >> 6;
+    for (int s = 0; s < 3; ++s) {
+        double v[3] = {0.0, 0.0, 0.0};
+        for (int b = a.blk_begin[s] + t; b < a.blk_begin[s + 1]; b += 256)
+            for (int k = 0; k < 3; ++k) v[k] += a.part[(size_t)b * 3 + k];
+        for (int k = 0; k < 3; ++k) {
+            double r = wave_sum_d(v[k]);
+            if ((t & 63) == 0) sh[s][k][w] = r;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        float total = 0.f, tb = 0.f, to = 0.f, tc = 0.f;
+        const float wobj[3] = {4.0f, 1.0f, 0.4f};
+        for (int s = 0; s < 3; ++s) {
+            double sb = sh[s][0][0] + sh[s][0][1] + sh[s][0][2] + sh[s][0][3];
+            double so = sh[s][1][0] + sh[s][1][1] + sh[s][1][2] + sh[s][1][3];
+            double sc = sh[s][2][0] + sh[s][2][1] + sh[s][2][2] + sh[s][2][3];
+            int n = a.counts[s];
+            float box = n > 0 ? (float)(sb / (double)n) : 0.f;
+            float obj = (float)(so / (double)a.cells[s]);
+            float cls = (n > 0 && a.nc > 0) ? (float)(sc / ((double)n * (double)a.nc)) : 0.f;
+            float weighted = 0.05f * box + wobj[s] * obj + 0.5f * cls;   // train.py:879
+            total += weighted; tb += box; to += obj; tc += cls;
+            a.out[4 + 3 * s + 0] = box; a.out[4 + 3 * s + 1] = obj; a.out[4 + 3 * s + 2] = cls;
+        }
+        a.out[0] = total; a.out[1] = tb; a.out[2] = to; a.out[3] = tc;
+    }
+}
+
+// ---- standalone decode -------------------------------------------------------------------------
+struct Anc3 { float v[6]; };
+__global__ void decode_kernel(const float *__restrict__ raw, float *__restrict__ out, const Anc3 ancs,
+                              int GH, int GW, int ch, float img, int64_t cells) {
+    const float *anc = ancs.v;
+    for (int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < cells;
+         cell += (int64_t)gridDim.x * blockDim.x) {
+        int an = (int)(cell % 3);
+        int64_t q = cell / 3;
+        int j = (int)(q % GW), i = (int)((q / GW) % GH);
+        const float *p = raw + cell * ch;
+        float *o = out + cell * ch;
+        float sx = yh_sigmoid(p[0]), sy = yh_sigmoid(p[1]), sw = yh_sigmoid(p[2]), sh = yh_sigmoid(p[3]);
+        o[0] = ((sx * 2.0f - 0.5f) + (float)j) / (float)GW;
+        o[1] = ((sy * 2.0f - 0.5f) + (float)i) / (float)GH;
+        float tw = 2.0f * sw, th = 2.0f * sh;
+        o[2] = (anc[an * 2 + 0] / img) * (tw * tw);
+        o[3] = (anc[an * 2 + 1] / img) * (th * th);
+        for (int c = 4; c < ch; ++c) o[c] = p[c];
+    }
+}
+__global__ void decode_bwd_kernel(const float *__restrict__ raw, const float *__restrict__ dout,
+                                  float *__restrict__ draw, const Anc3 ancs, int GH, int GW, int ch,
+                                  float img, int64_t cells) {
+    const float *anc = ancs.v;
+    for (int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < cells;
+         cell += (int64_t)gridDim.x * blockDim.x) {
+        int an = (int)(cell % 3);
+        const float *p = raw + cell * ch, *g = dout + cell * ch;
+        float *o = draw + cell * ch;
+        float sx = yh_sigmoid(p[0]), sy = yh_sigmoid(p[1]), sw = yh_sigmoid(p[2]), sh = yh_sigmoid(p[3]);
+        o[0] = g[0] * (2.0f * sx * (1.f - sx) / (float)GW);
+        o[1] = g[1] * (2.0f * sy * (1.f - sy) / (float)GH);
+        o[2] = g[2] * ((anc[an * 2 + 0] / img) * 8.0f * sw * sw * (1.f - sw));
+        o[3] = g[3] * ((anc[an * 2 + 1] / img) * 8.0f * sh * sh * (1.f - sh));
+        for (int c = 4; c < ch; ++c) o[c] = g[c];
+    }
+}
+
+// ---- standalone CIoU (mean over N) ---------------------------------------------------------------
+__global__ void ciou_kernel(const float *__restrict__ pred, const float *__restrict__ tgt, float *__restrict__ dpred,
+                            int64_t N, float eps, float gscale, double *__restrict__ part) {
+    __shared__ double red[4];
+    int64_t n = blockIdx.x * (int64_t)256 + threadIdx.x;
+    double l = 0.0;
+    if (n < N) {
+        float p[4] = {pred[4 * n], pred[4 * n + 1], pred[4 * n + 2], pred[4 * n + 3]};
+        float t[4] = {tgt[4 * n], tgt[4 * n + 1], tgt[4 * n + 2], tgt[4 * n + 3]}, g[4];
+        l = (double)ciou_term(p, t, eps, g);
+        if (dpred)
+            for (int e = 0; e < 4; ++e) dpred[4 * n + e] = g[e] * gscale / (float)N;
+    }
+    l = wave_sum_d(l);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void ciou_final_kernel(const double *__restrict__ part, int nblk, int64_t N, float *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[b];
+        out[0] = (float)(s / (double)N);
+    }
+}
+
+int fill_args(LossArgs &a, const float *const pred[3], const float *const target[3], float *const dpred[3],
+              const float *anchors, const int grid[3], int B, int nc, float img, float gscale, float *out, float *ws) {
+    YH_REQUIRE(pred && target && anchors && grid && out && ws && B > 0 && nc >= 0 && img > 0.f, "yolo_loss: bad argument");
+    int nb = 0;
+    for (int s = 0; s < 3; ++s) {
+        YH_REQUIRE(pred[s] && target[s] && grid[s] > 0, "yolo_loss: scale %d missing", s);
+        a.pred[s] = pred[s]; a.tgt[s] = target[s]; a.dpred[s] = dpred ? dpred[s] : nullptr;
+        a.grid[s] = grid[s];
+        a.cells[s] = (int64_t)B * grid[s] * grid[s] * 3;
+        a.blk_begin[s] = nb;
+        nb += (int)cdiv64(a.cells[s], 256);
+    }
+    a.blk_begin[3] = nb;
+    for (int k = 0; k < 18; ++k) a.anchors[k] = anchors[k];
+    a.B = B; a.nc = nc; a.img = img; a.gscale = gscale;
+    a.counts = (int *)ws;
+    a.part = (double *)(ws + 8);
+    a.out = out;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t yh_loss_ws(const int grid[3], int B) {
+    int64_t nb = 0;
+    for (int s = 0; s < 3; ++s) nb += cdiv64((int64_t)B * grid[s] * grid[s] * 3, 256);
+    return 8 + 6 * nb;
+}
+
+extern "C" int yh_yolo_loss(const float *const pred[3], const float *const target[3], float *const dpred[3],
+                            const float *anchors, const int grid[3], int B, int nc, float loss_img_size,
+                            float grad_scale, float *out, float *ws, void *stream) {
+    LossArgs a{};
+    int rc = fill_args(a, pred, target, dpred, anchors, grid, B, nc, loss_img_size, grad_scale, out, ws);
+    if (rc) return rc;
+    YH_REQUIRE(((uintptr_t)ws & 7) == 0, "yolo_loss: workspace must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    YH_HIP(hipMemsetAsync(a.counts, 0, 4 * sizeof(int), st));
+    const int ch = 5 + nc;
+    for (int s = 0; s < 3; ++s)
+        if (a.dpred[s]) YH_HIP(hipMemsetAsync(a.dpred[s], 0, (size_t)a.cells[s] * ch * sizeof(float), st));
+    const int nb = a.blk_begin[3];
+    hipLaunchKernelGGL(loss_count_kernel, dim3(nb), dim3(256), 0, st, a);
+    YH_CHECK_LAUNCH("loss_count");
+    hipLaunchKernelGGL(loss_main_kernel, dim3(nb), dim3(256), 0, st, a);
+    YH_CHECK_LAUNCH("loss_main");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, a);
+    YH_CHECK_LAUNCH("loss_final");
+    return 0;
+}
+
+static int decode_grid(int64_t cells) {
+    int64_t g = cdiv64(cells, 256);
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+extern "C" int yh_decode(const float *raw, float *out, const float *anchors3x2, int B, int GH, int GW, int nc,
+                         float img_size, void *stream) {
+    YH_REQUIRE(raw && out && anchors3x2 && B > 0 && GH > 0 && GW > 0 && nc >= 0 && img_size > 0.f, "decode: bad argument");
+    Anc3 an;
+    for (int k = 0; k < 6; ++k) an.v[k] = anchors3x2[k];
+    int64_t cells = (int64_t)B * GH * GW * 3;
+    hipLaunchKernelGGL(decode_kernel, dim3(decode_grid(cells)), dim3(256), 0, (hipStream_t)stream, raw, out, an, GH, GW,
+                       5 + nc, img_size, cells);
+    YH_CHECK_LAUNCH("decode");
+    return 0;
+}
+
+extern "C" int yh_decode_bwd(const float *raw, const float *dout, float *draw, const float *anchors3x2, int B, int GH,
+                             int GW, int nc, float img_size, void *stream) {
+    YH_REQUIRE(raw && dout && draw && anchors3x2 && B > 0 && GH > 0 && GW > 0 && nc >= 0, "decode_bwd: bad argument");
+    Anc3 an;
+    for (int k = 0; k < 6; ++k) an.v[k] = anchors3x2[k];
+    int64_t cells = (int64_t)B * GH * GW * 3;
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3(decode_grid(cells)), dim3(256), 0, (hipStream_t)stream, raw, dout, draw, an,
+                       GH, GW, 5 + nc, img_size, cells);
+    YH_CHECK_LAUNCH("decode_bwd");
+    return 0;
+}
+
+extern "C" int yh_ciou(const float *pred, const float *tgt, float *dpred, int64_t N, float eps, float grad_scale,
+                       float *loss_out, float *ws, void *stream) {
+    YH_REQUIRE(pred && tgt && loss_out && ws && N > 0, "ciou: bad argument (N must be > 0)");
+    YH_REQUIRE(((uintptr_t)ws & 7) == 0, "ciou: workspace must be 8-byte aligned");
+    int nblk = (int)cdiv64(N, 256);
+    hipLaunchKernelGGL(ciou_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, pred, tgt, dpred, N, eps, grad_scale,
+                       (double *)ws);
+    YH_CHECK_LAUNCH("ciou");
+    hipLaunchKernelGGL(ciou_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)ws, nblk, N, loss_out);
+    YH_CHECK_LAUNCH("ciou_final");
+    return 0;
+}
