@@ -104,16 +104,20 @@ int yh_maxpool5_bwd(const float *dy, int lddy, const uint8_t *argmax, float *dx,
                     int C, void *stream);
 
 /* ---- loss: decode + CIoU + BCE, three scales, forward and backward in one pass ----------------- */
-/* pred[s], target[s]: (B,G_s,G_s,3,5+nc) contiguous, G_s = grid[s] (pred/target/dpred/grid are HOST
- * arrays of device pointers / ints); anchors: HOST, 3x3x2 floats (pixels), captured by value.
+/* pred[s], target[s]: (B,G_s,G_s,3,5+nc) contiguous, G_s = grid[s]; grid[s] == 0 marks an absent scale
+ * (pred/target/dpred/grid are HOST arrays of device pointers / ints); anchors: HOST, 3x3x2 floats
+ * (pixels), captured by value.  loss_w / grad_w: HOST, 9 floats = per scale (box, obj, cls) weights of
+ * the total and of its gradient; NULL loss_w = the reference's {0.05, {4.0,1.0,0.4}, 0.5}
+ * (train.py:865,879), NULL grad_w = loss_w.
  * out[0..4) = total, sum box, sum obj (unweighted), sum cls (train.py:886); out[4+3s..] = per-scale
- * box/obj/cls.  dpred[s] (may be NULL -> forward only) receives d total / d pred[s] * grad_scale.
- * ws: >= yh_loss_ws(...) floats, 8-byte aligned.  loss_img_size is the decode img_size (reference: always 640, Q1).
+ * box/obj/cls.  dpred[s] (NULL array or NULL entry -> forward only) receives
+ * sum_k grad_w[s][k] * d loss_k / d pred[s].  ws: >= yh_loss_ws(...) floats, 8-byte aligned.
+ * loss_img_size is the decode img_size (reference: always 640, quirk Q1).
  * replaces: decode_predictions + ciou_loss + yolo_loss + yolo_loss_multiscale and their autograd
  * (train.py:634-886, 909, 913). */
 int yh_yolo_loss(const float *const pred[3], const float *const target[3], float *const dpred[3],
-                 const float *anchors, const int grid[3], int B, int nc, float loss_img_size, float grad_scale,
-                 float *out, float *ws, void *stream);
+                 const float *anchors, const int grid[3], int B, int nc, float loss_img_size, const float *loss_w,
+                 const float *grad_w, float *out, float *ws, void *stream);
 int64_t yh_loss_ws(const int grid[3], int B);
 /* Standalone pieces of the same math for the reference's public functions (anchors3x2: HOST).
  * yh_ciou: ws >= 2*ceil(N/256) floats, 8-byte aligned; N must be > 0. */
@@ -142,14 +146,15 @@ int yh_nms(const float *boxes, const float *scores, const int32_t *classes, cons
 int64_t yh_nms_ws(int cap);
 
 /* ---- optimiser: global-norm clip + Adam over flat buffers -------------------------------------- */
-/* norm_out[0] = ||g||_2 (fp32), deterministic two-stage reduce; ws >= yh_sqnorm_ws(n) doubles.
+/* norm_out[0] = grad_scale * ||g||_2 (fp32), deterministic two-stage fp64 reduce; ws >= yh_sqnorm_ws(n)
+ * doubles.  grad_scale = 1/world_size folds the data-parallel mean into the norm.
  * replaces: torch.nn.utils.clip_grad_norm_ (train.py:916). */
-int yh_grad_sqnorm(const float *g, int64_t n, float *norm_out, double *ws, void *stream);
+int yh_grad_sqnorm(const float *g, int64_t n, float grad_scale, float *norm_out, double *ws, void *stream);
 int64_t yh_sqnorm_ws(int64_t n);
-/* g *= min(1, max_norm/(norm+1e-6)) (skipped when max_norm <= 0 or norm == NULL), then one Adam
- * step (torch.optim.Adam defaults, step is 1-based).  replaces: train.py:916-918. */
+/* g *= grad_scale * min(1, max_norm/(norm+1e-6)) (the clip is skipped when max_norm <= 0 or norm == NULL),
+ * then one Adam step (torch.optim.Adam defaults, step is 1-based).  replaces: train.py:916-918. */
 int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
-                 float eps, int step, float max_norm, const float *norm, void *stream);
+                 float eps, int step, float max_norm, const float *norm, float grad_scale, void *stream);
 
 /* ---- small utilities (stream-ordered) --------------------------------------------------------------- */
 int yh_memset(void *p, int value, int64_t bytes, void *stream);

@@ -1,0 +1,71 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/yolohip.h declares, the
+module tree reproduces the reference's state-dict, and nothing silently falls back to the CPU."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from yolo_from_scratch_amd import _lib
+    names = _lib.declared_symbols()
+    assert len(names) >= 35 and "yh_conv_fwd" in names and "yh_nms" in names
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in yolohip.h but not exported"
+    assert set(_lib._SIGS) == set(names)                   # the python binding covers the whole ABI
+    assert _lib.lib().yh_version() >= 100
+    assert ctypes.sizeof(_lib.YhOp) == 4 + 80 + 16 + 4 + 96 + 16   # struct yh_op layout (with padding)
+
+
+def test_state_dict_contract_matches_reference():
+    import yolo_from_scratch_amd as y
+    g = load_golden("model_nc1")
+    torch.manual_seed(0)
+    m = y.YOLO(num_classes=1, img_size=640)
+    sd = m.state_dict()
+    assert len(sd) == 377 and list(sd.keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == 3662838
+    assert [v.numel() for v in sd.values()] == list(g["numel"])
+    np.testing.assert_array_equal([float(v.double().sum()) for v in sd.values()], g["init_sum"])
+    # grid buffers are contiguous so checkpoints round-trip (reference quirk Q5)
+    m2 = y.YOLO(num_classes=1)
+    m2.load_state_dict(sd)
+    assert all(v.is_contiguous() for v in sd.values())
+    assert m.head_p3[-1].bias is not None and abs(float(m.head_p3[-1].bias[4]) + 4.59512) < 1e-4
+    assert [tuple(a.shape) for a in m.anchors] == [(3, 2)] * 3
+    assert (m.grid_size_p3, m.grid_size_p4, m.grid_size_p5, m.output_channels) == (80, 40, 20, 18)
+
+
+@pytest.mark.parametrize("size,nc", [("n", 2), ("m", 1)])
+def test_other_sizes_construct(size, nc):
+    import yolo_from_scratch_amd as y
+    wm, dm = y.YOLO_SIZES[size]
+    m = y.YOLO(num_classes=nc, img_size=320, width_mult=wm, depth_mult=dm)
+    assert m.head_p5[-1].out_channels == 3 * (5 + nc)
+
+
+def test_product_refuses_cpu_tensors():
+    import yolo_from_scratch_amd as y
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        y.YOLO(num_classes=1, img_size=64)(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        y.decode_predictions(torch.zeros(1, 2, 2, 3, 6), torch.ones(3, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        y.batched_nms(torch.zeros(1, 4), torch.zeros(1), torch.zeros(1, dtype=torch.long), 0.5)
+
+
+def test_host_side_helpers_known_answers():
+    import yolo_from_scratch_amd as y
+    g = load_golden("nms")
+    ka = [tuple(r) for r in g["ka3/dets"]]
+    assert [ka.index(d) for d in y.nms(ka, 0.5)] == [0, 2]
+    assert y.nms([], 0.5) == []
+    assert abs(y.compute_iou_corners((0, 0, 10, 10), (5, 0, 15, 10)) - 1 / 3) < 1e-12
+    lam = y.get_lr_lambda(3, 100, 1e-2, 1e-4, 1e-6)
+    assert abs(lam(0) * 1e-2 - 1e-6) < 1e-12 and abs(lam(3) - 1.0) < 1e-9 and abs(lam(100) * 1e-2 - 1e-4) < 1e-9
+    a = torch.tensor([0.5, 0.5, 0.2, 0.2])
+    assert abs(float(y.compute_box_iou(a, a)) - 0.04 / (0.04 + 1e-6)) < 1e-6

@@ -1,0 +1,225 @@
+"""GPU parity of the individual C-ABI kernels against a plain fp64/fp32 torch CPU evaluation of the
+same op (conv fwd / bwd-data / bwd-weight on every layer shape family of the network, BN+SiLU, pool,
+Adam).  Tolerances: fp32 MFMA is an fmaf chain, so 1e-4 relative to the tensor's max magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    import yolo_from_scratch_amd._lib as L
+    return L
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(t):   # NCHW cpu -> NHWC cuda contiguous
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def rup4(c):
+    return (c + 3) // 4 * 4
+
+
+CONV_CASES = [  # (B, H, W, Cin, Cout, k, s, bias)  -- shape families of the 's' model at reduced size
+    (2, 32, 32, 3, 16, 3, 2, True),      # stem.0 (Cin padded to 4)
+    (2, 24, 24, 16, 32, 3, 2, True),     # stem.3
+    (2, 20, 20, 32, 16, 1, 1, False),    # C3 1x1 small
+    (2, 20, 20, 16, 16, 3, 1, False),    # bottleneck 16
+    (1, 16, 16, 64, 64, 3, 1, False),    # head 3x3
+    (1, 8, 8, 128, 128, 3, 1, False),
+    (1, 6, 6, 256, 256, 3, 1, False),
+    (1, 10, 10, 192, 64, 1, 1, False),   # panet conv (non power-of-two Cin)
+    (1, 6, 6, 384, 128, 1, 1, False),
+    (1, 6, 6, 512, 256, 1, 1, True),     # sppf.conv2
+    (2, 12, 12, 64, 64, 3, 2, False),    # downsample
+    (2, 9, 11, 32, 64, 3, 2, True),      # odd sizes, stride 2
+    (2, 10, 10, 64, 18, 1, 1, True),     # head out nc=1
+    (1, 10, 10, 128, 255, 1, 1, True),   # head out nc=80
+    (3, 7, 5, 8, 12, 3, 1, False),       # tiny odd
+    (1, 40, 40, 32, 32, 3, 1, False),    # M not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    L = _lib()
+    lib = L.lib()
+    B, H, W, Cin, Cout, k, s, has_bias = case
+    torch.manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout) if has_bias else None
+    p = k // 2
+    ref = F.conv2d(x.double(), w.double(), bias.double() if has_bias else None, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    cin = rup4(Cin)
+    st = torch.cuda.current_stream().cuda_stream
+    xg = torch.zeros(B, H, W, cin, device="cuda")
+    xg[..., :Cin] = nhwc(x)
+    wd = w.cuda()
+    ldwf, ldwb = rup4(Cout), cin
+    wf = torch.empty(k * k * cin * ldwf, device="cuda")
+    wb = torch.empty(k * k * Cout * ldwb, device="cuda")
+    L.check(lib.yh_pack_weights(wd.data_ptr(), wf.data_ptr(), wb.data_ptr(), Cout, Cin, k, cin, ldwf, ldwb, st))
+    # forward into a channel slice of a wider buffer (ld > C) with BN partial sums
+    ld = Cout + 8
+    ybuf = torch.full((B, Ho, Wo, ld), 7.0, device="cuda")
+    nblk = lib.yh_conv_fwd_blocks(B, H, W, Cout, k, s)
+    part = torch.zeros(nblk * 2 * Cout, device="cuda")
+    bd = bias.cuda() if has_bias else None
+    yview = ybuf.view(-1)[4:]
+    L.check(lib.yh_conv_fwd(xg.data_ptr(), cin, wf.data_ptr(), ldwf, bd.data_ptr() if has_bias else None,
+                            yview.data_ptr(), ld, part.data_ptr(), B, H, W, cin, Cout, k, s, st))
+    y = ybuf[..., 4:4 + Cout].permute(0, 3, 1, 2)
+    assert rel_err(y, ref) < 1e-4
+    assert float(ybuf[..., :4].min()) == 7.0 and float(ybuf[..., 4 + Cout:].min()) == 7.0   # neighbours untouched
+    ps = part.view(nblk, 2, Cout).double().sum(0).cpu()
+    assert rel_err(ps[0], ref.sum((0, 2, 3))) < 1e-3 * max(1.0, float(ref.abs().sum((0, 2, 3)).max() / (ref.sum((0, 2, 3)).abs().max() + 1e-9)))
+    assert rel_err(ps[1], (ref ** 2).sum((0, 2, 3))) < 1e-4
+    # backward
+    dy = torch.randn(B, Cout, Ho, Wo)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(xr, wr, None, s, p).backward(dy.double())
+    dyg = nhwc(dy)
+    dx = torch.full((B, H, W, cin), 3.0, device="cuda")
+    L.check(lib.yh_conv_bwd_data(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, dx.data_ptr(), cin, B, H, W, cin, Cout, k, s, 0, st))
+    assert rel_err(dx[..., :Cin].permute(0, 3, 1, 2), xr.grad) < 1e-4
+    L.check(lib.yh_conv_bwd_data(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, dx.data_ptr(), cin, B, H, W, cin, Cout, k, s, 1, st))
+    assert rel_err(dx[..., :Cin].permute(0, 3, 1, 2), 2 * xr.grad) < 1e-4        # accumulate flag
+    nws = lib.yh_conv_bwd_weight_ws(B, H, W, cin, Cout, k, s)
+    assert nws > 0
+    ws = torch.empty(nws, device="cuda")
+    dw = torch.zeros(Cout, Cin, k, k, device="cuda")
+    L.check(lib.yh_conv_bwd_weight(xg.data_ptr(), cin, dyg.data_ptr(), Cout, dw.data_ptr(), ws.data_ptr(), nws, B, H, W, cin,
+                                   Cin, Cout, k, s, st))
+    assert rel_err(dw, wr.grad) < 1e-4
+    if has_bias:
+        wsb = torch.empty(lib.yh_colsum_ws(B * Ho * Wo, Cout), device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        L.check(lib.yh_colsum(dyg.data_ptr(), Cout, B * Ho * Wo, Cout, db.data_ptr(), wsb.data_ptr(), st))
+        assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5
+
+
+def test_conv_rejects_bad_arguments():
+    L = _lib()
+    lib = L.lib()
+    t = torch.zeros(64, device="cuda")
+    assert lib.yh_conv_fwd(t.data_ptr(), 4, t.data_ptr(), 4, None, t.data_ptr(), 4, None, 1, 4, 4, 4, 4, 5, 1, 0) != 0
+    assert b"unsupported" in lib.yh_last_error()
+    assert lib.yh_conv_fwd(None, 4, t.data_ptr(), 4, None, t.data_ptr(), 4, None, 1, 4, 4, 4, 4, 3, 1, 0) != 0
+    with pytest.raises(RuntimeError):
+        L.check(lib.yh_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 0.0, None, 1.0, 0), "adam")
+
+
+@pytest.mark.parametrize("C,H,W,up,res", [(16, 9, 7, False, False), (64, 6, 6, True, False), (32, 8, 8, False, True),
+                                          (256, 4, 4, False, False), (12, 5, 5, False, True)])
+def test_bn_silu_fwd_bwd(C, H, W, up, res):
+    L = _lib()
+    lib = L.lib()
+    B = 3
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(C + H)
+    y = (torch.randn(B, C, H, W) * 2 + 0.5).double().requires_grad_(True)
+    gamma = (torch.rand(C) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(C) * 0.3).double().requires_grad_(True)
+    r = torch.randn(B, C, H, W).double().requires_grad_(True) if res else None
+    rm, rv = torch.zeros(C).double(), torch.ones(C).double()
+    z = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    a = F.silu(z)
+    if res:
+        a = a + r
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    f = 2 if up else 1
+    g = torch.randn(B, C, H * f, W * f).double()
+    a.backward(g)
+    M = B * H * W
+    yg = nhwc(y.detach().float())
+    # statistics through the same partial-sum interface the conv epilogue uses (1 block)
+    part = torch.stack([yg.view(M, C).sum(0), (yg.view(M, C) ** 2).sum(0)]).contiguous()
+    coef = torch.empty(4 * C, device="cuda")
+    rmg, rvg = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    gm, bt = gamma.detach().float().cuda(), beta.detach().float().cuda()
+    L.check(lib.yh_bn_finalize(part.data_ptr(), 1, M, gm.data_ptr(), bt.data_ptr(), rmg.data_ptr(), rvg.data_ptr(), 0.1, 1e-5,
+                               coef.data_ptr(), C, st))
+    assert rel_err(rmg, rm) < 1e-5 and rel_err(rvg, rv) < 1e-5
+    rg = nhwc(r.detach().float()) if res else None
+    out = torch.empty(B, H * f, W * f, C, device="cuda")
+    L.check(lib.yh_bn_silu_fwd(yg.data_ptr(), C, coef.data_ptr(), rg.data_ptr() if res else None, C, out.data_ptr(), C, M, C, H,
+                               W, int(up), st))
+    assert rel_err(out.permute(0, 3, 1, 2), a.detach()) < 1e-5
+    dag = nhwc(g.float())
+    nb = lib.yh_bn_bwd_blocks(M, C)
+    pb = torch.empty(nb * 2 * C, device="cuda")
+    L.check(lib.yh_bn_silu_bwd_reduce(dag.data_ptr(), C, yg.data_ptr(), C, coef.data_ptr(), pb.data_ptr(), M, C, H, W, int(up), st))
+    dgm, dbt = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dres = torch.ones(B, H, W, C, device="cuda") if res else None
+    dy = torch.empty_like(yg)
+    L.check(lib.yh_bn_silu_bwd_apply(dag.data_ptr(), C, yg.data_ptr(), C, coef.data_ptr(), pb.data_ptr(), nb, gm.data_ptr(),
+                                     dgm.data_ptr(), dbt.data_ptr(), dy.data_ptr(), C, dres.data_ptr() if res else None, C, 1, M,
+                                     C, H, W, int(up), st))
+    assert rel_err(dy.permute(0, 3, 1, 2), y.grad) < 2e-4
+    assert rel_err(dgm, gamma.grad) < 2e-4 and rel_err(dbt, beta.grad) < 2e-4
+    if res:
+        assert rel_err(dres.permute(0, 3, 1, 2) - 1.0, r.grad) < 1e-5      # accumulated onto the ones
+
+
+def test_maxpool5_chain_matches_torch_including_ties():
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, C, H, W = 2, 8, 11, 9
+    torch.manual_seed(5)
+    x = torch.randint(0, 4, (B, C, H, W)).double().requires_grad_(True)      # many exact ties
+    y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    g = torch.randn(B, 4 * C, H, W).double()
+    torch.cat([x, y1, y2, y3], 1).backward(g)
+    cat = torch.zeros(B, H, W, 4 * C, device="cuda")
+    cat[..., :C] = nhwc(x.detach().float())
+    args = [torch.empty(B, H, W, C, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    base = cat.data_ptr()
+    for i in range(3):
+        L.check(lib.yh_maxpool5_fwd(base + 4 * C * i, 4 * C, base + 4 * C * (i + 1), 4 * C, args[i].data_ptr(), B, H, W, C, st))
+    ref = torch.cat([x, y1, y2, y3], 1).detach()
+    assert rel_err(cat.permute(0, 3, 1, 2), ref) == 0.0
+    dcat = nhwc(g.float())
+    gb = dcat.data_ptr()
+    for i in (2, 1, 0):
+        L.check(lib.yh_maxpool5_bwd(gb + 4 * C * (i + 1), 4 * C, args[i].data_ptr(), gb + 4 * C * i, 4 * C, B, H, W, C, st))
+    assert rel_err(dcat[..., :C].permute(0, 3, 1, 2), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,world", [(1003, 1), (4096, 4)])
+def test_clip_adam_matches_oracle(n, world):
+    from oracle import yolo_oracle as orc
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(n)
+    npad = rup4(n)
+    p0, g0 = torch.randn(npad), torch.randn(npad) * 3
+    p, g = p0.clone().cuda(), g0.clone().cuda()
+    m, v = torch.zeros(npad, device="cuda"), torch.zeros(npad, device="cuda")
+    norm = torch.zeros(1, device="cuda")
+    ws = torch.empty(lib.yh_sqnorm_ws(npad) + 2, dtype=torch.float64, device="cuda")
+    pr, mr, vr = p0.clone(), torch.zeros(npad), torch.zeros(npad)
+    for step in (1, 2, 3):
+        L.check(lib.yh_grad_sqnorm(g.data_ptr(), npad, 1.0 / world, norm.data_ptr(), ws.data_ptr(), st))
+        gavg = g.cpu() / world
+        total, coef = orc.clip_coef([gavg], 10.0)
+        assert abs(float(norm) - total) / total < 1e-6
+        L.check(lib.yh_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), npad, 1e-3, 0.9, 0.999, 1e-8, step, 10.0,
+                                 norm.data_ptr(), 1.0 / world, st))
+        gr = gavg * coef
+        orc.adam_step(pr, gr, mr, vr, step, 1e-3)
+        assert rel_err(g, gr) < 1e-6            # clipped gradient is written back, as clip_grad_norm_ does
+        assert rel_err(p, pr) < 1e-6 and rel_err(m, mr) < 1e-6 and rel_err(v, vr) < 1e-6
+        g = (torch.randn(npad) * 3).cuda()

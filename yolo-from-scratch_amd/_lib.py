@@ -1,0 +1,125 @@
+"""ctypes binding of libyolohip.so (the C ABI declared in include/yolohip.h).
+
+The product path has no fallback: if the shared library is missing, or a call fails, a RuntimeError
+is raised.  Nothing here touches torch; callers pass raw device addresses (tensor.data_ptr()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolohip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "yolohip.h")
+
+c_fp = C.c_void_p   # device pointers travel as integers
+i32, i64, f32 = C.c_int, C.c_int64, C.c_float
+
+
+class YhOp(C.Structure):
+    """Mirror of `struct yh_op` (include/yolohip.h)."""
+    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 20), ("f", C.c_float * 4),
+                ("p", C.c_void_p * 12), ("l", C.c_int64 * 2)]
+
+
+# op kinds, same order as the enum in yolohip.h
+(OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_PACK_WEIGHTS, OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT,
+ OP_COLSUM, OP_BN_FINALIZE, OP_BN_EVAL_COEF, OP_BN_SILU_FWD, OP_BN_SILU_BWD_REDUCE, OP_BN_SILU_BWD_APPLY,
+ OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64) = range(1, 17)
+
+_P3 = C.c_void_p * 3
+_I3 = C.c_int * 3
+
+_SIGS = {
+    "yh_version": (i32, []),
+    "yh_last_error": (C.c_char_p, []),
+    "yh_nchw_to_nhwc": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_nhwc_to_nchw": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_pack_weights": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
+    "yh_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),
+    "yh_colsum": (i32, [c_fp, i32, i64, i32, c_fp, c_fp, c_fp]),
+    "yh_colsum_ws": (i64, [i64, i32]),
+    "yh_bn_finalize": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp]),
+    "yh_bn_eval_coef": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),
+    "yh_bn_silu_fwd": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bn_silu_bwd_reduce": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bn_bwd_blocks": (i32, [i64, i32]),
+    "yh_bn_silu_bwd_apply": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32,
+                                   i64, i32, i32, i32, i32, c_fp]),
+    "yh_maxpool5_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, c_fp]),
+    "yh_maxpool5_bwd": (i32, [c_fp, i32, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "yh_yolo_loss": (i32, [_P3, _P3, _P3, C.POINTER(f32), _I3, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp, c_fp]),
+    "yh_loss_ws": (i64, [_I3, i32]),
+    "yh_decode": (i32, [c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
+    "yh_decode_bwd": (i32, [c_fp, c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
+    "yh_ciou": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, c_fp, c_fp, c_fp]),
+    "yh_candidates": (i32, [_P3, C.POINTER(f32), _I3, i32, f32, f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, i32, c_fp,
+                            c_fp]),
+    "yh_candidates_ws": (i64, [_I3]),
+    "yh_nms": (i32, [c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp, c_fp, c_fp, c_fp]),
+    "yh_nms_ws": (i64, [i32]),
+    "yh_grad_sqnorm": (i32, [c_fp, i64, f32, c_fp, c_fp, c_fp]),
+    "yh_sqnorm_ws": (i64, [i64]),
+    "yh_adam_step": (i32, [c_fp, c_fp, c_fp, c_fp, i64, f32, f32, f32, f32, i32, f32, c_fp, f32, c_fp]),
+    "yh_memset": (i32, [c_fp, i32, i64, c_fp]),
+    "yh_add_int64": (i32, [c_fp, i64, c_fp]),
+    "yh_run": (i32, [C.POINTER(YhOp), i32, c_fp, C.POINTER(i32)]),
+}
+
+_lib = None
+
+
+def declared_symbols() -> list:
+    """Every function name include/yolohip.h declares (used by the CPU-side ABI test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(yh_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load libyolohip.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension must be built first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().yh_last_error().decode(errors="replace")
+        raise RuntimeError(f"libyolohip {what} failed (code {rc}): {msg}")
+
+
+def ptr3(tensors):
+    """HOST array of three device pointers (None -> NULL)."""
+    return _P3(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+
+def int3(vals):
+    return _I3(*[int(v) for v in vals])
+
+
+def floats(vals):
+    arr = (f32 * len(vals))(*[float(v) for v in vals])
+    return arr
+
+
+def run_ops(ops, n: int, stream: int):
+    failed = i32(-1)
+    rc = lib().yh_run(ops, n, stream, C.byref(failed))
+    if rc != 0:
+        msg = lib().yh_last_error().decode(errors="replace")
+        raise RuntimeError(f"libyolohip op #{failed.value} (kind {ops[failed.value].kind}) failed (code {rc}): {msg}")

@@ -120,7 +120,8 @@ struct LossArgs {
     int64_t cells[3];       // B*G*G*3 per scale
     int blk_begin[4];       // workgroup ranges per scale
     int B, nc;
-    float img, gscale;
+    float img;
+    float lw[9], gw[9];     // per scale (box, obj, cls): weights of the total, and of its gradient
     int *counts;            // [4]
     double *part;           // [nblk][3]
     float *out;             // [13]
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
     const int s = blockIdx.x >= a.blk_begin[2] ? 2 : (blockIdx.x >= a.blk_begin[1] ? 1 : 0);
     const int64_t cell = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256 + threadIdx.x;
     const int ch = 5 + a.nc, G = a.grid[s];
-    const float wobj = s == 0 ? 4.0f : (s == 1 ? 1.0f : 0.4f);
+    const float gbox = a.gw[3 * s + 0], gobj = a.gw[3 * s + 1], gcls = a.gw[3 * s + 2];
     const int npos = a.counts[s];
     double lbox = 0.0, lobj = 0.0, lcls = 0.0;
     if (cell < a.cells[s]) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
         float *d = a.dpred[s] ? a.dpred[s] + cell * ch : nullptr;
         const float x = p[4], z = t[4];
         lobj = (double)bce_logits(x, z);
-        if (d) d[4] = (yh_sigmoid(x) - z) * (wobj / (float)a.cells[s]) * a.gscale;
+        if (d) d[4] = (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]);
         if (z > 0.5f) {
             int an = (int)(cell % 3);
             int64_t q = cell / 3;
@@ -167,13 +168,13 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
             box[3] = ah * (two_h * two_h);
             lbox = (double)ciou_term(box, tb, 1e-7f, gb);
             if (d) {
-                float kb = 0.05f / (float)npos * a.gscale;
+                float kb = gbox / (float)npos;
                 d[0] = gb[0] * (2.0f * sg[0] * (1.f - sg[0]) / (float)G) * kb;
                 d[1] = gb[1] * (2.0f * sg[1] * (1.f - sg[1]) / (float)G) * kb;
                 d[2] = gb[2] * (aw * 8.0f * sg[2] * sg[2] * (1.f - sg[2])) * kb;
                 d[3] = gb[3] * (ah * 8.0f * sg[3] * sg[3] * (1.f - sg[3])) * kb;
             }
-            float kc = a.nc > 0 ? 0.5f / ((float)npos * (float)a.nc) * a.gscale : 0.f;
+            float kc = a.nc > 0 ? gcls / ((float)npos * (float)a.nc) : 0.f;
             for (int c = 0; c < a.nc; ++c) {
                 float xc = p[5 + c], zc = t[5 + c];
                 lcls += (double)bce_logits(xc, zc);
@@ -205,8 +206,8 @@ __global__ void loss_final_kernel(const LossArgs a) {
     __syncthreads();
     if (t == 0) {
         float total = 0.f, tb = 0.f, to = 0.f, tc = 0.f;
-        const float wobj[3] = {4.0f, 1.0f, 0.4f};
         for (int s = 0; s < 3; ++s) {
+            if (a.cells[s] == 0) { a.out[4 + 3 * s] = a.out[5 + 3 * s] = a.out[6 + 3 * s] = 0.f; continue; }
             double sb = sh[s][0][0] + sh[s][0][1] + sh[s][0][2] + sh[s][0][3];
             double so = sh[s][1][0] + sh[s][1][1] + sh[s][1][2] + sh[s][1][3];
             double sc = sh[s][2][0] + sh[s][2][1] + sh[s][2][2] + sh[s][2][3];
@@ -214,7 +215,7 @@ __global__ void loss_final_kernel(const LossArgs a) {
             float box = n > 0 ? (float)(sb / (double)n) : 0.f;
             float obj = (float)(so / (double)a.cells[s]);
             float cls = (n > 0 && a.nc > 0) ? (float)(sc / ((double)n * (double)a.nc)) : 0.f;
-            float weighted = 0.05f * box + wobj[s] * obj + 0.5f * cls;   // train.py:879
+            float weighted = a.lw[3 * s] * box + a.lw[3 * s + 1] * obj + a.lw[3 * s + 2] * cls;   // train.py:879 / 836
             total += weighted; tb += box; to += obj; tc += cls;
             a.out[4 + 3 * s + 0] = box; a.out[4 + 3 * s + 1] = obj; a.out[4 + 3 * s + 2] = cls;
         }
@@ -288,11 +289,12 @@ __global__ void ciou_final_kernel(const double *__restrict__ part, int nblk, int
 }
 
 int fill_args(LossArgs &a, const float *const pred[3], const float *const target[3], float *const dpred[3],
-              const float *anchors, const int grid[3], int B, int nc, float img, float gscale, float *out, float *ws) {
+              const float *anchors, const int grid[3], int B, int nc, float img, const float *loss_w,
+              const float *grad_w, float *out, float *ws) {
     YH_REQUIRE(pred && target && anchors && grid && out && ws && B > 0 && nc >= 0 && img > 0.f, "yolo_loss: bad argument");
     int nb = 0;
     for (int s = 0; s < 3; ++s) {
-        YH_REQUIRE(pred[s] && target[s] && grid[s] > 0, "yolo_loss: scale %d missing", s);
+        YH_REQUIRE(grid[s] >= 0 && (grid[s] == 0 || (pred[s] && target[s])), "yolo_loss: scale %d missing", s);
         a.pred[s] = pred[s]; a.tgt[s] = target[s]; a.dpred[s] = dpred ? dpred[s] : nullptr;
         a.grid[s] = grid[s];
         a.cells[s] = (int64_t)B * grid[s] * grid[s] * 3;
@@ -301,7 +303,10 @@ int fill_args(LossArgs &a, const float *const pred[3], const float *const target
     }
     a.blk_begin[3] = nb;
     for (int k = 0; k < 18; ++k) a.anchors[k] = anchors[k];
-    a.B = B; a.nc = nc; a.img = img; a.gscale = gscale;
+    static const float kDefault[9] = {0.05f, 4.0f, 0.5f, 0.05f, 1.0f, 0.5f, 0.05f, 0.4f, 0.5f};   // train.py:865,879
+    const float *lw = loss_w ? loss_w : kDefault, *gw = grad_w ? grad_w : lw;
+    for (int k = 0; k < 9; ++k) { a.lw[k] = lw[k]; a.gw[k] = gw[k]; }
+    a.B = B; a.nc = nc; a.img = img;
     a.counts = (int *)ws;
     a.part = (double *)(ws + 8);
     a.out = out;
@@ -318,9 +323,9 @@ extern "C" int64_t yh_loss_ws(const int grid[3], int B) {
 
 extern "C" int yh_yolo_loss(const float *const pred[3], const float *const target[3], float *const dpred[3],
                             const float *anchors, const int grid[3], int B, int nc, float loss_img_size,
-                            float grad_scale, float *out, float *ws, void *stream) {
+                            const float *loss_w, const float *grad_w, float *out, float *ws, void *stream) {
     LossArgs a{};
-    int rc = fill_args(a, pred, target, dpred, anchors, grid, B, nc, loss_img_size, grad_scale, out, ws);
+    int rc = fill_args(a, pred, target, dpred, anchors, grid, B, nc, loss_img_size, loss_w, grad_w, out, ws);
     if (rc) return rc;
     YH_REQUIRE(((uintptr_t)ws & 7) == 0, "yolo_loss: workspace must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -329,6 +334,7 @@ extern "C" int yh_yolo_loss(const float *const pred[3], const float *const targe
     for (int s = 0; s < 3; ++s)
         if (a.dpred[s]) YH_HIP(hipMemsetAsync(a.dpred[s], 0, (size_t)a.cells[s] * ch * sizeof(float), st));
     const int nb = a.blk_begin[3];
+    YH_REQUIRE(nb > 0, "yolo_loss: no cells");
     hipLaunchKernelGGL(loss_count_kernel, dim3(nb), dim3(256), 0, st, a);
     YH_CHECK_LAUNCH("loss_count");
     hipLaunchKernelGGL(loss_main_kernel, dim3(nb), dim3(256), 0, st, a);

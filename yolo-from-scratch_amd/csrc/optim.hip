@@ -26,25 +26,27 @@ __global__ void sqnorm_stage1(const float *__restrict__ g, int64_t n, double *__
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void sqnorm_stage2(const double *__restrict__ part, int nblk, float *__restrict__ out) {
+__global__ void sqnorm_stage2(const double *__restrict__ part, int nblk, double scale, float *__restrict__ out) {
     __shared__ double red[4];
     double s = 0.0;
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += part[b];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) out[0] = (float)(scale * sqrt(red[0] + red[1] + red[2] + red[3]));
 }
 
 __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                             int64_t n, float b1, float b2, float eps, float step_size, float bc2_sqrt, float max_norm,
-                            const float *__restrict__ norm) {
+                            const float *__restrict__ norm, float gscale) {
     float coef = 1.f;
     const bool clip = norm != nullptr && max_norm > 0.f;
     if (clip) {
         coef = max_norm / (norm[0] + 1e-6f);
         if (coef > 1.f) coef = 1.f;
     }
+    const bool write_g = clip || gscale != 1.f;
+    coef *= gscale;
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 gv = *(const f32x4 *)(g + 4 * i), mv = *(const f32x4 *)(m + 4 * i);
@@ -58,7 +60,7 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
             float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
             pv[e] = pv[e] - step_size * (mv[e] / denom);
         }
-        if (clip) *(f32x4 *)(g + 4 * i) = gv;
+        if (write_g) *(f32x4 *)(g + 4 * i) = gv;
         *(f32x4 *)(m + 4 * i) = mv;
         *(f32x4 *)(v + 4 * i) = vv;
         *(f32x4 *)(p + 4 * i) = pv;
@@ -66,7 +68,7 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         int64_t i = (n4 << 2) + threadIdx.x;
         float ge = g[i] * coef;
-        if (clip) g[i] = ge;
+        if (write_g) g[i] = ge;
         float me = m[i] + (ge - m[i]) * (1.f - b1);
         float ve = v[i] * b2 + (1.f - b2) * ge * ge;
         m[i] = me; v[i] = ve;
@@ -78,20 +80,20 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
 
 extern "C" int64_t yh_sqnorm_ws(int64_t n) { (void)n; return kNormBlocks; }
 
-extern "C" int yh_grad_sqnorm(const float *g, int64_t n, float *norm_out, double *ws, void *stream) {
+extern "C" int yh_grad_sqnorm(const float *g, int64_t n, float grad_scale, float *norm_out, double *ws, void *stream) {
     YH_REQUIRE(g && norm_out && ws && n > 0, "grad_sqnorm: bad argument");
     YH_REQUIRE(((uintptr_t)g & 15) == 0, "grad_sqnorm: buffer must be 16-byte aligned");
     int64_t want = cdiv64(n / 4 + 1, 256);
     int nblk = (int)(want > kNormBlocks ? kNormBlocks : want);
     hipLaunchKernelGGL(sqnorm_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, n, ws);
     YH_CHECK_LAUNCH("sqnorm_stage1");
-    hipLaunchKernelGGL(sqnorm_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, nblk, norm_out);
+    hipLaunchKernelGGL(sqnorm_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, nblk, (double)grad_scale, norm_out);
     YH_CHECK_LAUNCH("sqnorm_stage2");
     return 0;
 }
 
 extern "C" int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
-                            float eps, int step, float max_norm, const float *norm, void *stream) {
+                            float eps, int step, float max_norm, const float *norm, float grad_scale, void *stream) {
     YH_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
     YH_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -99,7 +101,7 @@ extern "C" int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, f
     int64_t want = cdiv64(n / 4 + 1, 256);
     int nblk = (int)(want > 2048 ? 2048 : want);
     hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
-                       step_size, bc2_sqrt, max_norm, norm);
+                       step_size, bc2_sqrt, max_norm, norm, grad_scale);
     YH_CHECK_LAUNCH("adam");
     return 0;
 }

@@ -1,0 +1,340 @@
+"""Static network plans over NHWC buffers: the host-side scheduler of the HIP kernels.
+
+A module tree is *traced once* per (input shape, mode) into a list of layer records over symbolic
+NHWC buffers; the records are lowered to two flat op lists (forward, backward) of `yh_op` structs
+holding raw device pointers.  Running a step is then two C calls (`yh_run`) -- no per-layer Python,
+no autograd graph, no allocation -- which is what makes the lists hipGraph-friendly.
+
+Design points (all about HBM traffic, the bound for this small-channel network):
+  * torch.cat never materialises: producers write straight into channel slices of a shared buffer
+    (a view = buffer + channel offset, ld = buffer channels);
+  * nearest-x2 upsampling is folded into the producer's BN+SiLU write, the residual add into the
+    same pass; the head outputs are already (B,G,G,3,5+nc) because the layout is NHWC;
+  * BatchNorm statistics come out of the conv epilogue; dY overwrites Y in place in the backward.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+BN_EPS_DEFAULT = 1e-5
+
+
+def _rup4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class Buffer:
+    """An NHWC fp32 activation tensor (B,H,W,C) plus, lazily, its gradient tensor."""
+
+    def __init__(self, plan: "Plan", B: int, H: int, W: int, C: int, name: str):
+        self.plan, self.B, self.H, self.W, self.C, self.name = plan, B, H, W, C, name
+        self.data = torch.empty(B, H, W, C, device=plan.device, dtype=torch.float32)
+        self._grad: Optional[torch.Tensor] = None
+        self.grad_cover: List[Tuple[int, int]] = []   # channel ranges already written in this backward
+
+    @property
+    def grad(self) -> torch.Tensor:
+        if self._grad is None:
+            self._grad = torch.empty_like(self.data)
+        return self._grad
+
+    def view(self, off: int = 0, C: Optional[int] = None) -> "View":
+        return View(self, off, self.C - off if C is None else C)
+
+
+@dataclass
+class View:
+    buf: Buffer
+    off: int
+    C: int
+
+    @property
+    def B(self): return self.buf.B
+    @property
+    def H(self): return self.buf.H
+    @property
+    def W(self): return self.buf.W
+    @property
+    def ld(self): return self.buf.C
+    @property
+    def M(self): return self.buf.B * self.buf.H * self.buf.W
+    def ptr(self) -> int: return self.buf.data.data_ptr() + 4 * self.off
+    def gptr(self) -> int: return self.buf.grad.data_ptr() + 4 * self.off
+
+
+@dataclass
+class ConvRec:
+    """conv (+bias) [+ BatchNorm + SiLU (+residual) (+x2 upsample on write)]"""
+    x: View
+    out: View
+    weight: torch.nn.Parameter
+    bias: Optional[torch.nn.Parameter]
+    bn: Optional[torch.nn.BatchNorm2d]
+    k: int
+    s: int
+    residual: Optional[View] = None
+    upsample: bool = False
+    # filled by the planner
+    cin: int = 0            # padded input channels seen by the kernels
+    cout: int = 0
+    Ho: int = 0
+    Wo: int = 0
+    y: Optional[torch.Tensor] = None        # raw conv output (B,Ho,Wo,cout); dY overwrites it in the backward
+    coef: Optional[torch.Tensor] = None
+    part: Optional[torch.Tensor] = None
+    wf: Optional[torch.Tensor] = None
+    wb: Optional[torch.Tensor] = None
+    ldwf: int = 0
+    ldwb: int = 0
+    need_dx: bool = True
+
+
+@dataclass
+class PoolRec:
+    x: View
+    out: View
+    arg: Optional[torch.Tensor] = None
+
+
+class Plan:
+    """Trace target + compiled op lists for one module at one input shape / mode."""
+
+    def __init__(self, device: torch.device, in_shape: Tuple[int, int, int, int], training: bool, need_input_grad: bool):
+        self.device, self.training, self.need_input_grad = device, training, need_input_grad
+        self.B, self.Cimg, self.Himg, self.Wimg = in_shape
+        self.recs: List[object] = []
+        self.buffers: List[Buffer] = []
+        self.outputs: List[Tuple[View, str]] = []       # (view, "nhwc_heads" | "nchw")
+        self.input = self.new_buffer(self.B, self.Himg, self.Wimg, _rup4(self.Cimg), "input")
+        self.generation = 0
+        self.fwd_ops = self.bwd_ops = None
+        self.param_ptrs: List[int] = []
+
+    # ---- tracing API used by the modules ------------------------------------------------------
+    def new_buffer(self, B, H, W, C, name="act") -> Buffer:
+        b = Buffer(self, B, H, W, C, name)
+        self.buffers.append(b)
+        return b
+
+    def conv(self, x: View, conv: torch.nn.Conv2d, bn: Optional[torch.nn.BatchNorm2d], out: Optional[View] = None,
+             residual: Optional[View] = None, upsample: bool = False) -> View:
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        if conv.kernel_size[0] != conv.kernel_size[1] or k not in (1, 3) or s not in (1, 2) or p != k // 2 \
+                or conv.stride[0] != conv.stride[1] or conv.groups != 1 or conv.dilation != (1, 1):
+            raise NotImplementedError(f"HIP conv path supports square k in (1,3), stride in (1,2), padding k//2; got {conv}")
+        if (k, s) == (1, 2):
+            raise NotImplementedError("1x1 stride-2 convolutions are not part of this network")
+        if conv.in_channels != x.C and _rup4(conv.in_channels) != x.C:
+            raise ValueError(f"conv expects {conv.in_channels} input channels, got a view with {x.C}")
+        Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
+        cout = conv.out_channels
+        if bn is not None and cout % 4:
+            raise NotImplementedError("Conv+BN+SiLU on the HIP path needs out_channels % 4 == 0")
+        f = 2 if upsample else 1
+        if out is None:
+            out = self.new_buffer(x.B, Ho * f, Wo * f, cout if bn is None else _rup4(cout)).view()
+        if (out.H, out.W, out.C) != (Ho * f, Wo * f, cout):
+            raise ValueError(f"output view {(out.H, out.W, out.C)} does not match conv result {(Ho * f, Wo * f, cout)}")
+        if residual is not None and (residual.H, residual.W, residual.C) != (Ho, Wo, cout):
+            raise ValueError("residual shape mismatch")
+        self.recs.append(ConvRec(x, out, conv.weight, conv.bias, bn, k, s, residual, upsample, cin=x.C, cout=cout,
+                                 Ho=Ho, Wo=Wo))
+        return out
+
+    def pool5(self, x: View, out: View) -> View:
+        if x.C % 4 or (x.H, x.W, x.C) != (out.H, out.W, out.C):
+            raise ValueError("pool5: shape mismatch or channels not a multiple of 4")
+        self.recs.append(PoolRec(x, out))
+        return out
+
+    def mark_output(self, v: View, kind: str):
+        self.outputs.append((v, kind))
+
+    # ---- lowering -----------------------------------------------------------------------------
+    def params(self) -> List[torch.nn.Parameter]:
+        seen, out = set(), []
+        for r in self.recs:
+            if isinstance(r, ConvRec):
+                for p in (r.weight, r.bias, r.bn.weight if r.bn is not None else None,
+                          r.bn.bias if r.bn is not None else None):
+                    if p is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        out.append(p)
+        return out
+
+    def compile(self, grad_of: Optional[Dict[int, torch.Tensor]] = None):
+        """Allocate per-layer scratch and emit the op lists.  grad_of maps id(param) -> tensor that
+        receives its gradient (views of a flat buffer); required when training."""
+        lib = L.lib()
+        dev = self.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        fwd: List[L.YhOp] = []
+        keep: List[torch.Tensor] = []          # tensors referenced only through raw pointers
+        for r in self.recs:
+            if isinstance(r, ConvRec):
+                kk = r.k * r.k
+                r.ldwf, r.ldwb = _rup4(r.cout), _rup4(r.cin)
+                r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
+                r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
+                r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
+                fwd.append(_op(L.OP_PACK_WEIGHTS, p=[r.weight, r.wf, r.wb],
+                               i=[r.cout, r.weight.shape[1], r.k, r.cin, r.ldwf, r.ldwb]))
+                if r.bn is not None:
+                    r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32)
+                    r.coef = torch.empty(4 * r.cout, **f32)
+                    ytarget, ldy = r.y, r.cout
+                else:
+                    ytarget, ldy = None, r.out.ld
+                nblk = lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
+                M = r.x.B * r.Ho * r.Wo
+                if r.bn is not None and self.training:
+                    nb_bwd = lib.yh_bn_bwd_blocks(M, r.cout)
+                    r.part = torch.empty(max(nblk, nb_bwd) * 2 * r.cout, **f32)
+                if r.bn is not None and not self.training:
+                    fwd.append(_op(L.OP_BN_EVAL_COEF, p=[r.bn.weight, r.bn.bias, r.bn.running_mean, r.bn.running_var, r.coef],
+                                   i=[r.cout], f=[r.bn.eps]))
+                fwd.append(_op(L.OP_CONV_FWD,
+                               p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
+                                  r.part if (r.bn is not None and self.training) else None],
+                               i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s]))
+                if r.bn is not None:
+                    if self.training:
+                        track = r.bn.track_running_stats and r.bn.running_mean is not None
+                        mom = r.bn.momentum if r.bn.momentum is not None else 0.1
+                        fwd.append(_op(L.OP_BN_FINALIZE,
+                                       p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
+                                          r.bn.running_var if track else None, r.coef],
+                                       i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M]))
+                        if track and r.bn.num_batches_tracked is not None:
+                            fwd.append(_op(L.OP_ADD_INT64, p=[r.bn.num_batches_tracked], l=[1]))
+                    fwd.append(_op(L.OP_BN_SILU_FWD,
+                                   p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
+                                   i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
+                                      int(r.upsample)], l=[M]))
+            else:
+                r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
+                fwd.append(_op(L.OP_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
+                               i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C]))
+        self.fwd_ops = _pack(fwd)
+        self.bwd_ops = _pack(self._lower_backward(grad_of, keep)) if self.training else None
+        self._keep = keep
+        self.param_ptrs = [p.data_ptr() for p in self.params()]
+
+    def _grad_target(self, v: View) -> Tuple[int, int]:
+        """Pointer into the gradient tensor of `v` and whether the op must accumulate."""
+        cov = v.buf.grad_cover
+        lo, hi = v.off, v.off + v.C
+        inside = any(a <= lo and hi <= b for a, b in cov)
+        overlap = any(a < hi and lo < b for a, b in cov)
+        if inside:
+            return v.gptr(), 1
+        if overlap:
+            raise NotImplementedError(f"partial gradient overlap on buffer {v.buf.name}")
+        cov.append((lo, hi))
+        return v.gptr(), 0
+
+    def _lower_backward(self, grad_of, keep) -> List[L.YhOp]:
+        lib = L.lib()
+        if grad_of is None:
+            raise ValueError("training plan needs gradient destinations")
+        for b in self.buffers:
+            b.grad_cover = []
+        # gradients of the declared outputs arrive from outside (loss kernel / autograd) fully written
+        for v, _ in self.outputs:
+            v.buf.grad_cover.append((v.off, v.off + v.C))
+        ws_floats = 1
+        for r in self.recs:
+            if isinstance(r, ConvRec):
+                ws_floats = max(ws_floats, lib.yh_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
+                if r.bias is not None:
+                    ws_floats = max(ws_floats, lib.yh_colsum_ws(r.x.B * r.Ho * r.Wo, r.cout))
+        self.ws = torch.empty(int(ws_floats), device=self.device, dtype=torch.float32)
+        ops: List[L.YhOp] = []
+        self.grad_ready: Dict[int, int] = {}     # id(param) -> number of backward ops after which its grad is final
+        for r in reversed(self.recs):
+            if isinstance(r, PoolRec):
+                dst, acc = self._grad_target(r.x)
+                if not acc:
+                    raise NotImplementedError("max-pool backward expects an already written input gradient")
+                ops.append(_op(L.OP_MAXPOOL5_BWD, p=[r.out.gptr(), r.arg, dst], i=[r.out.ld, r.x.ld, r.x.B, r.x.H, r.x.W, r.x.C]))
+                continue
+            M = r.x.B * r.Ho * r.Wo
+            if r.bn is not None:
+                nb = lib.yh_bn_bwd_blocks(M, r.cout)
+                ops.append(_op(L.OP_BN_SILU_BWD_REDUCE, p=[r.out.gptr(), r.y, r.coef, r.part],
+                               i=[r.out.ld, r.cout, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                if r.residual is not None:
+                    dres, racc = self._grad_target(r.residual)
+                    ldres = r.residual.ld
+                else:
+                    dres, racc, ldres = None, 0, 0
+                ops.append(_op(L.OP_BN_SILU_BWD_APPLY,
+                               p=[r.out.gptr(), r.y, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)],
+                                  grad_of[id(r.bn.bias)], r.y, dres],
+                               i=[r.out.ld, r.cout, nb, r.cout, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                dy, lddy = r.y.data_ptr(), r.cout
+                self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
+            else:
+                dy, lddy = r.out.gptr(), r.out.ld
+            if r.bias is not None:
+                ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
+                self.grad_ready[id(r.bias)] = len(ops)
+            ops.append(_op(L.OP_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+                           i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
+                           l=[self.ws.numel()]))
+            self.grad_ready[id(r.weight)] = len(ops)
+            if r.need_dx:
+                dst, acc = self._grad_target(r.x)
+                ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
+                               i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
+        return ops
+
+    # ---- execution ----------------------------------------------------------------------------
+    def params_moved(self) -> bool:
+        return [p.data_ptr() for p in self.params()] != self.param_ptrs
+
+    def run_forward(self, stream: int):
+        L.run_ops(self.fwd_ops[0], self.fwd_ops[1], stream)
+        self.generation += 1
+
+    def run_backward(self, stream: int, begin: int = 0, end: Optional[int] = None):
+        """Run backward ops [begin, end) (the trainer splits the list at gradient-bucket boundaries)."""
+        arr, n = self.bwd_ops
+        end = n if end is None else end
+        if end > begin:
+            L.run_ops(ctypes.cast(ctypes.byref(arr, begin * ctypes.sizeof(L.YhOp)), ctypes.POINTER(L.YhOp)), end - begin, stream)
+
+
+def _addr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def _op(kind: int, p=(), i=(), f=(), l=()) -> L.YhOp:
+    o = L.YhOp()
+    o.kind = kind
+    for n, v in enumerate(p):
+        o.p[n] = _addr(v)
+    for n, v in enumerate(i):
+        o.i[n] = int(v)
+    for n, v in enumerate(f):
+        o.f[n] = float(v)
+    for n, v in enumerate(l):
+        o.l[n] = int(v)
+    return o
+
+
+def _pack(ops: List[L.YhOp]):
+    arr = (L.YhOp * max(len(ops), 1))()
+    for n, o in enumerate(ops):
+        arr[n] = o
+    return arr, len(ops)

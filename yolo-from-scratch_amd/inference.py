@@ -1,0 +1,104 @@
+"""Inference post-process on the HIP path: candidate extraction + class-aware global NMS
+(train.py:1114-1250), plus `predict` with the reference's signature.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .functional import _anchors18
+from .hostside import letterbox_resize
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class Detector:
+    """Fixed-capacity device buffers + the two kernels of the post-process.  Everything stays on the
+    device until `fetch`; capacity = every cell of the three grids, so nothing is ever truncated."""
+
+    def __init__(self, grids: Sequence[int], num_classes: int, device):
+        L.lib()
+        self.grids, self.nc, self.device = [int(g) for g in grids], int(num_classes), device
+        self.cap = sum(3 * g * g for g in self.grids)
+        i32 = dict(device=device, dtype=torch.int32)
+        self.boxes = torch.empty(self.cap, 4, device=device, dtype=torch.float32)
+        self.scores = torch.empty(self.cap, device=device, dtype=torch.float32)
+        self.classes = torch.empty(self.cap, **i32)
+        self.count = torch.zeros(1, **i32)
+        self.keep = torch.empty(self.cap, **i32)
+        self.nkeep = torch.zeros(1, **i32)
+        self.ws_c = torch.empty(int(L.lib().yh_candidates_ws(L.int3(self.grids))) + 4, **i32)
+        self.ws_n = torch.empty(int(L.lib().yh_nms_ws(self.cap)) + 256, device=device, dtype=torch.uint8)
+
+    def candidates(self, preds: Sequence[torch.Tensor], anchors_list, img_size, conf_threshold, pad_left=0.0,
+                   pad_top=0.0, scale=1.0):
+        for p, g in zip(preds, self.grids):
+            if tuple(p.shape) != (1, g, g, 3, 5 + self.nc) or not p.is_contiguous():
+                raise ValueError(f"expected contiguous (1,{g},{g},3,{5 + self.nc}) predictions, got {tuple(p.shape)}")
+        L.check(L.lib().yh_candidates(L.ptr3(preds), L.floats(_anchors18(anchors_list)), L.int3(self.grids), self.nc,
+                                      float(img_size), float(conf_threshold), float(pad_left), float(pad_top),
+                                      float(scale), self.boxes.data_ptr(), self.scores.data_ptr(),
+                                      self.classes.data_ptr(), self.count.data_ptr(), self.cap, self.ws_c.data_ptr(),
+                                      _stream(self.device)), "candidates")
+
+    def nms(self, iou_threshold: float):
+        L.check(L.lib().yh_nms(self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr(),
+                               self.count.data_ptr(), self.cap, float(iou_threshold), self.keep.data_ptr(),
+                               self.nkeep.data_ptr(), self.ws_n.data_ptr(), _stream(self.device)), "nms")
+
+    def fetch(self) -> List[Tuple[float, float, float, float, float, int]]:
+        m, k = int(self.count.item()), int(self.nkeep.item())
+        if m > self.cap:
+            raise RuntimeError("candidate capacity exceeded")
+        idx = self.keep[:k].long()
+        b = self.boxes[idx].cpu().tolist()
+        s = self.scores[idx].cpu().tolist()
+        c = self.classes[idx].cpu().tolist()
+        return [(bb[0], bb[1], bb[2], bb[3], ss, int(cc)) for bb, ss, cc in zip(b, s, c)]
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Same contract as torchvision.ops.batched_nms (the reference's call, train.py:1232-1233): kept
+    indices (int64) in descending-score order, suppression only within a class, IoU > threshold."""
+    if not boxes.is_cuda:
+        raise RuntimeError("batched_nms: the HIP path needs GPU tensors; no CPU fallback in this package")
+    M = int(boxes.shape[0])
+    if M == 0:
+        return torch.zeros(0, dtype=torch.int64, device=boxes.device)
+    dev = boxes.device
+    b = boxes.contiguous().float()
+    s = scores.contiguous().float()
+    c = idxs.contiguous().to(torch.int32)
+    count = torch.tensor([M], device=dev, dtype=torch.int32)
+    keep = torch.empty(M, device=dev, dtype=torch.int32)
+    nkeep = torch.zeros(1, device=dev, dtype=torch.int32)
+    ws = torch.empty(int(L.lib().yh_nms_ws(M)) + 256, device=dev, dtype=torch.uint8)
+    L.check(L.lib().yh_nms(b.data_ptr(), s.data_ptr(), c.data_ptr(), count.data_ptr(), M, float(iou_threshold),
+                           keep.data_ptr(), nkeep.data_ptr(), ws.data_ptr(), _stream(dev)), "nms")
+    return keep[: int(nkeep.item())].long()
+
+
+def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_threshold=0.4):
+    """Letterbox -> model (eval) -> decode/threshold -> un-letterbox -> global class-aware NMS; returns
+    [(x1,y1,x2,y2,conf,class_id)] in original-image pixels (train.py:1114-1250)."""
+    from PIL import Image
+    model.eval()
+    pil = Image.open(image_path).convert("RGB")
+    img_size = model.img_size
+    pil, scale, pad_top, pad_left = letterbox_resize(pil, img_size)
+    x = (torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0).unsqueeze(0).to(device)
+    with torch.no_grad():
+        preds = model(x)
+    det = getattr(model, "_detector", None)
+    grids = [p.shape[1] for p in preds]
+    if det is None or det.grids != grids or det.nc != num_classes or det.device != preds[0].device:
+        det = Detector(grids, num_classes, preds[0].device)
+        model._detector = det
+    det.candidates(preds, model.anchors, img_size, conf_threshold, pad_left, pad_top, scale)
+    det.nms(iou_threshold)
+    return det.fetch()

@@ -1,0 +1,233 @@
+"""Training step on the HIP path: fused trainer (no autograd, no per-step host sync), the HipAdam
+optimizer facade, data-parallel gradient averaging over RCCL, and the reference's train_epoch /
+eval_epoch signatures (train.py:888-1032).
+
+One training step = NCHW->NHWC, forward op list, fused loss kernel (writes d loss / d head outputs),
+backward op list (split at gradient-bucket boundaries when data-parallel so each bucket's all-reduce
+runs on RCCL's stream under the remaining backward kernels), global-norm + clip + Adam over flat
+buffers.  Loss scalars stay on the device; callers read them when they want to.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .functional import _OBJ_W, _W_BOX, _W_CLS, _anchors18, run_loss_kernel, yolo_loss_multiscale
+from .functional import decode_predictions
+from .hostside import compute_box_iou, stack_targets
+from .modules import HipModule
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class HipTrainer:
+    """Owns the flat parameter / gradient / Adam-state buffers of a YOLO model and runs fused steps."""
+
+    def __init__(self, model: HipModule, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = 10.0,
+                 process_group=None, n_buckets: int = 4):
+        self.model = model
+        params = list(model.parameters())
+        if not params or not params[0].is_cuda:
+            raise RuntimeError("HipTrainer: move the model to the GPU first; there is no CPU fallback")
+        L.lib()
+        self.device = params[0].device
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.step_count = 0
+        views = model._grad_views(self.device)           # flat gradient buffer, 4-float padded per tensor
+        self.flat_g = model._flat_grad
+        n = self.flat_g.numel()
+        self.flat_p = torch.zeros(n, device=self.device, dtype=torch.float32)
+        self.offsets = {}
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                dst = self.flat_p[off:off + p.numel()].view_as(p)
+                dst.copy_(p.data)
+                p.data = dst                              # parameters now live in the flat buffer
+                p.grad = views[id(p)]                     # and their .grad in the flat gradient buffer
+                self.offsets[id(p)] = (off, p.numel())
+                off += (p.numel() + 3) // 4 * 4
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.norm = torch.zeros(1, device=self.device, dtype=torch.float32)
+        self.norm_ws = torch.empty(int(L.lib().yh_sqnorm_ws(n)) + 2, device=self.device, dtype=torch.float64)
+        self.loss_out = torch.zeros(13, device=self.device, dtype=torch.float32)
+        self._loss_ws = None
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.n_buckets = max(1, n_buckets)
+        self._segments = None
+        self._params = params
+        if self.world > 1:
+            dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)      # identical replicas
+
+    # ---- data-parallel bucketing ----------------------------------------------------------------
+    def _plan_segments(self, plan):
+        """Split the flat gradient buffer into contiguous buckets (registration order) and find, for
+        each, the backward-op index after which all of its gradients are final."""
+        n_ops = plan.bwd_ops[1]
+        if self.world == 1:
+            return [(n_ops, None)]
+        total = self.flat_g.numel()
+        target = total / self.n_buckets
+        buckets, start, ready = [], 0, 0
+        for p in self._params:
+            off, numel = self.offsets[id(p)]
+            end = off + (numel + 3) // 4 * 4
+            ready = max(ready, plan.grad_ready[id(p)])
+            if end - start >= target and len(buckets) < self.n_buckets - 1:
+                buckets.append((ready, (start, end)))
+                start, ready = end, 0
+        if start < total:
+            buckets.append((ready, (start, total)))
+        buckets.sort(key=lambda b: b[0])          # earliest-complete bucket first (heads, then neck, then backbone)
+        segs = [(rdy, rng) for rdy, rng in buckets]
+        if segs[-1][0] < n_ops:
+            segs.append((n_ops, None))
+        return segs
+
+    # ---- one step -------------------------------------------------------------------------------
+    def step(self, imgs: torch.Tensor, targets: Sequence[torch.Tensor]) -> torch.Tensor:
+        """imgs (B,3,S,S) fp32 on the device, targets = three (B,G,G,3,5+nc) device tensors.
+        Returns the device tensor [total, box, obj, cls, ...per-scale] of this step (no host sync)."""
+        model = self.model
+        if not model.training:
+            model.train()
+        st = _stream(self.device)
+        plan = model._plan_for(imgs)
+        if self._segments is None or self._segments[0] is not plan:
+            self._segments = (plan, self._plan_segments(plan))
+            grids = [v.H for v, _ in plan.outputs]
+            self._loss_ws = torch.empty(int(L.lib().yh_loss_ws(L.int3(grids), plan.B)) + 8, device=self.device,
+                                        dtype=torch.float32)
+        model._load_input(plan, imgs)
+        plan.run_forward(st)
+        heads = [v for v, _ in plan.outputs]
+        nc = model.num_classes
+        run_loss_kernel([v.buf.data for v in heads], [t.contiguous() for t in targets], [v.buf.grad for v in heads],
+                        _anchors18(model.anchors), [v.H for v in heads], plan.B, nc, None, None, self.loss_out,
+                        self._loss_ws, st)
+        works, begin = [], 0
+        for end, rng in self._segments[1]:
+            plan.run_backward(st, begin, end)
+            begin = end
+            if rng is not None and self.world > 1:
+                works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        self.apply_update()
+        return self.loss_out
+
+    def apply_update(self):
+        """Global-norm clip (max_norm) + Adam over the flat buffers; averages over ranks when DP."""
+        st = _stream(self.device)
+        lib = L.lib()
+        n = self.flat_g.numel()
+        gscale = 1.0 / self.world
+        self.step_count += 1
+        clip = self.max_norm is not None and self.max_norm > 0
+        if clip:
+            L.check(lib.yh_grad_sqnorm(self.flat_g.data_ptr(), n, gscale, self.norm.data_ptr(), self.norm_ws.data_ptr(), st),
+                    "grad_sqnorm")
+        L.check(lib.yh_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), n,
+                                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                 self.step_count, float(self.max_norm) if clip else 0.0,
+                                 self.norm.data_ptr() if clip else None, gscale, st), "adam_step")
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Optimizer facade over HipTrainer: `HipAdam(model, lr=...)` behaves like
+    `optim.Adam(model.parameters(), lr=...)` (train.py:1506) but steps through the fused HIP kernel
+    on flat buffers; `max_norm` folds clip_grad_norm_(…, 10.0) (train.py:916) into the same launch."""
+
+    def __init__(self, model: HipModule, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = None,
+                 process_group=None):
+        self.trainer = HipTrainer(model, lr, betas, eps, max_norm, process_group)
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.trainer.flat_g.zero_()          # gradients live in one flat buffer; keep the views alive
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.trainer.lr, self.trainer.betas, self.trainer.eps = g["lr"], g["betas"], g["eps"]
+        self.trainer.apply_update()
+
+    def fused_step(self, imgs, targets):
+        g = self.param_groups[0]
+        self.trainer.lr, self.trainer.betas, self.trainer.eps = g["lr"], g["betas"], g["eps"]
+        return self.trainer.step(imgs, targets)
+
+
+def train_epoch(model, loader, optimizer, device, num_classes=1):
+    """One epoch; returns mean (total, box, obj, cls) over batches (train.py:888-926).  With a HipAdam
+    optimizer every batch is one fused HIP step (clip 10.0 + Adam included) and the loss scalars are
+    read back once per epoch; with any other torch optimizer the same kernels run under autograd and
+    the reference's clip_grad_norm_(10.0) / optimizer.step() sequence is followed literally."""
+    model.train()
+    anchors_list = model.anchors
+    n = 0
+    if isinstance(optimizer, HipAdam):
+        if optimizer.trainer.max_norm is None:
+            optimizer.trainer.max_norm = 10.0
+        acc = torch.zeros(4, device=device, dtype=torch.float64)
+        for imgs, targets in loader:
+            out = optimizer.fused_step(imgs.to(device, non_blocking=True), stack_targets(targets, device))
+            acc += out[:4].double()
+            n += 1
+        vals = (acc / max(n, 1)).tolist()
+        return vals[0], vals[1], vals[2], vals[3]
+    tot = [0.0, 0.0, 0.0, 0.0]
+    for imgs, targets in loader:
+        imgs = imgs.to(device)
+        tb = stack_targets(targets, device)
+        optimizer.zero_grad()
+        preds = model(imgs)
+        loss, lb, lo, lc = yolo_loss_multiscale(preds, tb, anchors_list, num_classes)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)
+        optimizer.step()
+        for k, v in enumerate((loss, lb, lo, lc)):
+            tot[k] += v.item()
+        n += 1
+    return tuple(t / n for t in tot)
+
+
+def eval_epoch(model, loader, device, num_classes=1, iou_threshold=0.5, conf_threshold=0.5):
+    """Validation loss + same-cell/same-anchor precision, recall, F1 in percent (train.py:960-1032).
+    The reference walks every cell in Python; here the identical counting rule is evaluated with
+    tensor masks on the device."""
+    model.eval()
+    anchors_list = model.anchors
+    total_loss, tp, fp, fn, nb = 0.0, 0, 0, 0, 0
+    with torch.no_grad():
+        for imgs, targets in loader:
+            imgs = imgs.to(device)
+            tb = stack_targets(targets, device)
+            preds = model(imgs)
+            total_loss += yolo_loss_multiscale(preds, tb, anchors_list, num_classes)[0].item()
+            nb += 1
+            for pred, tgt, anc in zip(preds, tb, anchors_list):
+                dec = decode_predictions(pred, anc)
+                pobj = torch.sigmoid(pred[..., 4]) > conf_threshold
+                tobj = tgt[..., 4] > conf_threshold
+                both = pobj & tobj
+                if bool(both.any()):
+                    pb, tbx = dec[..., 0:4][both], tgt[..., 0:4][both]
+                    iou = compute_box_iou(pb.t(), tbx.t())
+                    hit = int((iou > iou_threshold).sum())
+                    tp += hit
+                    fp += int(both.sum()) - hit
+                fp += int((pobj & ~tobj).sum())
+                fn += int((~pobj & tobj).sum())
+    prec = tp / (tp + fp) if tp + fp > 0 else 0
+    rec = tp / (tp + fn) if tp + fn > 0 else 0
+    f1 = 2 * prec * rec / (prec + rec) if prec + rec > 0 else 0
+    return total_loss / max(nb, 1), prec * 100, rec * 100, f1 * 100
