@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of one full training step (NCHW->NHWC, forward, fused loss, backward,
+[gradient all-reduce], global-norm clip 10.0, Adam) on synthetic 640x640 batches, bs=64 per GPU, fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]           (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every forward-conv
+launch (the gather-GEMM kernel) on the stream it runs on, in instrumented steps right after the timed
+region; `cpu_baseline` times the CPU oracle (a port of the reference step on stock torch CPU ops) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NC, IMG, BATCH = 1, 640, 64          # BASELINE.json configs[1]
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def plan_conv_flops(plan):
+    from yolo_from_scratch_amd.graph import ConvRec
+    fl = 0
+    for r in plan.recs:
+        if isinstance(r, ConvRec):
+            fl += 2 * r.weight.shape[1] * r.cout * r.k * r.k * r.Ho * r.Wo
+    return fl   # per image
+
+
+def time_forward_convs(trainer, plan, imgs, targets, steps):
+    """HIP-event time of every OP_CONV_FWD launch (and, separately, of every op class) per step."""
+    from yolo_from_scratch_amd import _lib as L
+    import ctypes
+    dev = trainer.device
+    arr, n = plan.fwd_ops
+    st = torch.cuda.current_stream(dev).cuda_stream
+    conv_ms, n_launch = 0.0, 0
+    per_kind = {}
+    for _ in range(steps):
+        trainer.model._load_input(plan, imgs)
+        evs = []
+        for k in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.run_ops(ctypes.cast(ctypes.byref(arr, k * ctypes.sizeof(L.YhOp)), ctypes.POINTER(L.YhOp)), 1, st)
+            e1.record()
+            evs.append((arr[k].kind, e0, e1))
+        torch.cuda.synchronize(dev)
+        for kind, e0, e1 in evs:
+            ms = e0.elapsed_time(e1)
+            per_kind[kind] = per_kind.get(kind, 0.0) + ms
+            if kind == L.OP_CONV_FWD:
+                conv_ms += ms
+                n_launch += 1
+        plan.generation += 1
+    return conv_ms / steps, n_launch // steps, {k: v / steps for k, v in per_kind.items()}
+
+
+def cpu_baseline(batch=8, steps=3):
+    """The CPU oracle's training step (same math on stock torch CPU ops) on a bounded sample."""
+    from oracle import yolo_oracle as orc
+    import yolo_from_scratch_amd as y
+    torch.manual_seed(0)
+    m = y.YOLO(num_classes=NC, img_size=IMG)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    params = [P[n].requires_grad_(True) for n, _ in m.named_parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    x = torch.rand(batch, 3, IMG, IMG, generator=torch.Generator().manual_seed(1000))
+    tg = y.synthetic_targets(batch, NC, IMG, 8, 2000)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = orc.loss_multiscale(orc.forward(P, x, NC, True), tg, orc.anchors_of(P), NC)[0]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(batch / t, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"median of {steps} full training steps at batch {batch} (of {BATCH}) after 1 warm-up, same model/inputs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import yolo_from_scratch_amd as y
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)                                   # identical replicas
+    model = y.YOLO(num_classes=NC, img_size=IMG).to(dev)
+    trainer = y.HipTrainer(model, lr=1e-3, max_norm=10.0)
+    imgs = torch.rand(BATCH, 3, IMG, IMG, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    targets = [t.to(dev) for t in y.synthetic_targets(BATCH, NC, IMG, 8, 2000 + rank)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(imgs, targets)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(imgs, targets)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = trainer.loss_out[:4].tolist()
+
+    result = {
+        "metric": "images/sec training step, 640x640 bs=64/GPU", "value": round(BATCH * world * args.steps / elapsed, 2),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "nc=1 640x640 bs=64/GPU full training step (fwd+loss+bwd+clip10+Adam), model size s, fp32 MFMA",
+                   "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+        "loss": [round(v, 6) for v in loss],
+    }
+    if rank == 0 and not args.no_roofline:
+        plan = model._plan_for(imgs)
+        conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
+        flops = plan_conv_flops(plan) * BATCH
+        ach = flops / (conv_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                              "kernel": "gather_gemm_kernel (forward convolutions)", "launches_per_step": n_launch,
+                              "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
+        result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -153,8 +153,8 @@ int yh_grad_sqnorm(const float *g, int64_t n, float grad_scale, float *norm_out,
 int64_t yh_sqnorm_ws(int64_t n);
 /* g *= grad_scale * min(1, max_norm/(norm+1e-6)) (the clip is skipped when max_norm <= 0 or norm == NULL),
  * then one Adam step (torch.optim.Adam defaults, step is 1-based).  replaces: train.py:916-918. */
-int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
-                 float eps, int step, float max_norm, const float *norm, float grad_scale, void *stream);
+int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
+                 double eps, int step, float max_norm, const float *norm, float grad_scale, void *stream);
 
 /* ---- small utilities (stream-ordered) --------------------------------------------------------------- */
 int yh_memset(void *p, int value, int64_t bytes, void *stream);

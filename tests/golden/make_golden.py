@@ -288,7 +288,7 @@ def gen_candidates():
                 for _ in range(3):
                     m(torch.rand(2, 3, 640, 640))
                 for hd in (m.head_p3, m.head_p4, m.head_p5):
-                    hd[-1].weight.mul_(40.0)
+                    hd[-1].weight.mul_(60.0)
             del thr  # chosen below from the output distribution so that M is a few thousand
             rng = np.random.default_rng(801 + nc)
             img = rng.integers(0, 256, size=(size[1], size[0], 3), dtype=np.uint8)
@@ -299,7 +299,14 @@ def gen_candidates():
             m.eval()
             with torch.no_grad():
                 objs = torch.cat([torch.sigmoid(q[..., 4]).flatten() for q in m(x0)])
-            thr = float(torch.sort(objs, descending=True).values[2500])   # an exact fp32 value
+            # threshold in the widest gap between neighbouring objectness values near rank 2500, so that
+            # 1-ulp differences between sigmoid implementations cannot move a cell across it
+            srt = torch.sort(objs, descending=True).values.double()
+            gaps = (srt[800:6000] - srt[801:6001])
+            k = 800 + int(torch.argmax(gaps))
+            thr = float(((srt[k] + srt[k + 1]) / 2).float())
+            print(f"    threshold {thr!r}: gap {float(gaps.max()):.3e} = {float(gaps.max()) / 1.5e-8:.0f} fp32 ulps")
+            assert float(gaps.max()) > 64 * 1.5e-8, "no safe threshold gap"
             _Recorder.calls.clear()
             dets = ref.predict(m, p, torch.device("cpu"), nc, conf_threshold=thr, iou_threshold=0.4)
             boxes, scores, classes, _ = _Recorder.calls[-1]

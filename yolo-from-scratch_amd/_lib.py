@@ -30,6 +30,8 @@ class YhOp(C.Structure):
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
+_PP = C.POINTER(C.c_void_p)     # HOST array of device pointers (None -> NULL)
+_IP = C.POINTER(C.c_int)
 
 _SIGS = {
     "yh_version": (i32, []),
@@ -53,19 +55,19 @@ _SIGS = {
                                    i64, i32, i32, i32, i32, c_fp]),
     "yh_maxpool5_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, c_fp]),
     "yh_maxpool5_bwd": (i32, [c_fp, i32, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
-    "yh_yolo_loss": (i32, [_P3, _P3, _P3, C.POINTER(f32), _I3, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp, c_fp]),
-    "yh_loss_ws": (i64, [_I3, i32]),
+    "yh_yolo_loss": (i32, [_PP, _PP, _PP, C.POINTER(f32), _IP, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp, c_fp]),
+    "yh_loss_ws": (i64, [_IP, i32]),
     "yh_decode": (i32, [c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
     "yh_decode_bwd": (i32, [c_fp, c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
     "yh_ciou": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, c_fp, c_fp, c_fp]),
-    "yh_candidates": (i32, [_P3, C.POINTER(f32), _I3, i32, f32, f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, i32, c_fp,
+    "yh_candidates": (i32, [_PP, C.POINTER(f32), _IP, i32, f32, f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, i32, c_fp,
                             c_fp]),
-    "yh_candidates_ws": (i64, [_I3]),
+    "yh_candidates_ws": (i64, [_IP]),
     "yh_nms": (i32, [c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp, c_fp, c_fp, c_fp]),
     "yh_nms_ws": (i64, [i32]),
     "yh_grad_sqnorm": (i32, [c_fp, i64, f32, c_fp, c_fp, c_fp]),
     "yh_sqnorm_ws": (i64, [i64]),
-    "yh_adam_step": (i32, [c_fp, c_fp, c_fp, c_fp, i64, f32, f32, f32, f32, i32, f32, c_fp, f32, c_fp]),
+    "yh_adam_step": (i32, [c_fp, c_fp, c_fp, c_fp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, c_fp, f32, c_fp]),
     "yh_memset": (i32, [c_fp, i32, i64, c_fp]),
     "yh_add_int64": (i32, [c_fp, i64, c_fp]),
     "yh_run": (i32, [C.POINTER(YhOp), i32, c_fp, C.POINTER(i32)]),

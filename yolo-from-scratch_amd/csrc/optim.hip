@@ -37,8 +37,8 @@ __global__ void sqnorm_stage2(const double *__restrict__ part, int nblk, double 
 }
 
 __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                            int64_t n, float b1, float b2, float eps, float step_size, float bc2_sqrt, float max_norm,
-                            const float *__restrict__ norm, float gscale) {
+                            int64_t n, float omb1, float b2, float omb2, float eps, float step_size, float bc2_sqrt,
+                            float max_norm, const float *__restrict__ norm, float gscale) {
     float coef = 1.f;
     const bool clip = norm != nullptr && max_norm > 0.f;
     if (clip) {
@@ -55,8 +55,8 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
         for (int e = 0; e < 4; ++e) {
             float ge = gv[e] * coef;
             gv[e] = ge;
-            mv[e] = mv[e] + (ge - mv[e]) * (1.f - b1);                 // lerp_(grad, 1-beta1)
-            vv[e] = vv[e] * b2 + (1.f - b2) * ge * ge;
+            mv[e] = mv[e] + (ge - mv[e]) * omb1;                       // lerp_(grad, 1-beta1)
+            vv[e] = vv[e] * b2 + omb2 * ge * ge;
             float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
             pv[e] = pv[e] - step_size * (mv[e] / denom);
         }
@@ -69,8 +69,8 @@ __global__ void adam_kernel(float *__restrict__ p, float *__restrict__ g, float 
         int64_t i = (n4 << 2) + threadIdx.x;
         float ge = g[i] * coef;
         if (write_g) g[i] = ge;
-        float me = m[i] + (ge - m[i]) * (1.f - b1);
-        float ve = v[i] * b2 + (1.f - b2) * ge * ge;
+        float me = m[i] + (ge - m[i]) * omb1;
+        float ve = v[i] * b2 + omb2 * ge * ge;
         m[i] = me; v[i] = ve;
         p[i] = p[i] - step_size * (me / (sqrtf(ve) / bc2_sqrt + eps));
     }
@@ -92,16 +92,16 @@ extern "C" int yh_grad_sqnorm(const float *g, int64_t n, float grad_scale, float
     return 0;
 }
 
-extern "C" int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
-                            float eps, int step, float max_norm, const float *norm, float grad_scale, void *stream) {
+extern "C" int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
+                            double eps, int step, float max_norm, const float *norm, float grad_scale, void *stream) {
     YH_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
     YH_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
-    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     int64_t want = cdiv64(n / 4 + 1, 256);
     int nblk = (int)(want > 2048 ? 2048 : want);
-    hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
-                       step_size, bc2_sqrt, max_norm, norm, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, max_norm, norm, grad_scale);
     YH_CHECK_LAUNCH("adam");
     return 0;
 }

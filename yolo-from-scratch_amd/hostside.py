@@ -179,3 +179,33 @@ def compute_optimal_anchors(dataset_yaml, img_size=640, num_anchors=9):
     c = c[np.argsort(c[:, 0] * c[:, 1])]
     out = [[int(round(w)), int(round(h))] for w, h in c]
     return [out[0:3], out[3:6], out[6:9]]
+
+
+def synthetic_targets(batch, num_classes, img_size, n_obj=8, seed=2000, anchors=None):
+    """Seeded synthetic labels (centres U(0.05,0.95)^2, log-uniform w,h in [8,320] px,
+    uniform class) assigned to the three target grids with YOLODataset's rule.  Host code, built once
+    before the timed region; returns three (B,G,G,3,5+nc) CPU tensors."""
+    rng = np.random.default_rng(seed)
+    anc = [torch.tensor(a, dtype=torch.float32) for a in (anchors or DEFAULT_ANCHORS)]
+    grids = [img_size // 8, img_size // 16, img_size // 32]
+    out = [torch.zeros(batch, g, g, 3, 5 + num_classes) for g in grids]
+    for b in range(batch):
+        ctr = rng.uniform(0.05, 0.95, size=(n_obj, 2))
+        wh = np.exp(rng.uniform(math.log(8), math.log(320), size=(n_obj, 2))) / img_size
+        cls = rng.integers(0, max(num_classes, 1), size=n_obj)
+        for o in range(n_obj):
+            xc, yc, w, h = float(ctr[o, 0]), float(ctr[o, 1]), float(wh[o, 0]), float(wh[o, 1])
+            box = torch.tensor([w * img_size, h * img_size])
+            best, bs, ba = -1.0, 0, 0
+            for s in range(3):
+                iou = shape_iou(box, anc[s])
+                if iou.max().item() > best:
+                    best, bs, ba = iou.max().item(), s, int(iou.argmax())
+            g = grids[bs]
+            gx, gy = min(int(xc * g), g - 1), min(int(yc * g), g - 1)
+            t = out[bs][b]
+            if t[gy, gx, ba, 4] == 0:
+                t[gy, gx, ba, 0:4] = torch.tensor([xc, yc, w, h])
+                t[gy, gx, ba, 4] = 1.0
+                t[gy, gx, ba, 5 if num_classes == 1 else 5 + int(cls[o])] = 1.0
+    return out
