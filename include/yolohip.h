@@ -67,11 +67,12 @@ int64_t yh_colsum_ws(int64_t M, int C);
 /* ---- BatchNorm2d + SiLU ----------------------------------------------------------------------- */
 /* Reduce conv-epilogue partials to batch mean / biased variance; write scale = gamma*invstd and
  * shift = beta - mean*scale into coef[0..C) / coef[C..2C), mean / invstd into coef[2C..4C);
- * update running_mean / running_var (unbiased) with `momentum` when running_mean != NULL.
+ * update running_mean / running_var (unbiased) with `momentum` when running_mean != NULL and
+ * increment *num_batches_tracked when it is != NULL.
  * replaces: nn.BatchNorm2d training-mode statistics (train.py:261,265; torch native_batch_norm). */
 int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
-                   void *stream);
+                   int64_t *num_batches_tracked, void *stream);
 /* Inference coefficients from running statistics (BN folded to scale/shift). */
 int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
                     float eps, float *coef, int C, void *stream);
@@ -178,8 +179,12 @@ enum {
     YH_OP_ADD_INT64
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
- * (failing index in *failed when non-NULL). */
+ * (failing index in *failed when non-NULL).  Backward-weight and column-sum ops are forked onto an
+ * internal side stream (they only feed the optimiser) and joined back into `stream` before the call
+ * returns, so stream order is preserved for the caller; yh_set_overlap(0) (or YH_OVERLAP=0) disables
+ * the fork. */
 int yh_run(const yh_op *ops, int n, void *stream, int *failed);
+int yh_set_overlap(int enable);
 
 #ifdef __cplusplus
 }

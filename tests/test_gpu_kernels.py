@@ -149,7 +149,7 @@ def test_bn_silu_fwd_bwd(C, H, W, up, res):
     rmg, rvg = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     gm, bt = gamma.detach().float().cuda(), beta.detach().float().cuda()
     L.check(lib.yh_bn_finalize(part.data_ptr(), 1, M, gm.data_ptr(), bt.data_ptr(), rmg.data_ptr(), rvg.data_ptr(), 0.1, 1e-5,
-                               coef.data_ptr(), C, st))
+                               coef.data_ptr(), C, None, st))
     assert rel_err(rmg, rm) < 1e-5 and rel_err(rvg, rv) < 1e-5
     rg = nhwc(r.detach().float()) if res else None
     out = torch.empty(B, H * f, W * f, C, device="cuda")

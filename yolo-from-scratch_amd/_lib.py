@@ -46,7 +46,7 @@ _SIGS = {
     "yh_conv_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "yh_colsum": (i32, [c_fp, i32, i64, i32, c_fp, c_fp, c_fp]),
     "yh_colsum_ws": (i64, [i64, i32]),
-    "yh_bn_finalize": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp]),
+    "yh_bn_finalize": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp, c_fp]),
     "yh_bn_eval_coef": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),
     "yh_bn_silu_fwd": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "yh_bn_silu_bwd_reduce": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
@@ -71,6 +71,7 @@ _SIGS = {
     "yh_memset": (i32, [c_fp, i32, i64, c_fp]),
     "yh_add_int64": (i32, [c_fp, i64, c_fp]),
     "yh_run": (i32, [C.POINTER(YhOp), i32, c_fp, C.POINTER(i32)]),
+    "yh_set_overlap": (i32, [i32]),
 }
 
 _lib = None

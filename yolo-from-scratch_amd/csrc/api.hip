@@ -1,6 +1,7 @@
 // Error reporting, version and the op-list executor of libyolohip.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -45,7 +46,7 @@ static int run_one(const yh_op &o, void *st) {
             return yh_colsum((const float *)p[0], i[0], o.l[0], i[1], (float *)p[1], (float *)p[2], st);
         case YH_OP_BN_FINALIZE:
             return yh_bn_finalize((const float *)p[0], i[0], o.l[0], (const float *)p[1], (const float *)p[2],
-                                  (float *)p[3], (float *)p[4], f[0], f[1], (float *)p[5], i[1], st);
+                                  (float *)p[3], (float *)p[4], f[0], f[1], (float *)p[5], i[1], (int64_t *)p[6], st);
         case YH_OP_BN_EVAL_COEF:
             return yh_bn_eval_coef((const float *)p[0], (const float *)p[1], (const float *)p[2], (const float *)p[3], f[0],
                                    (float *)p[4], i[0], st);
@@ -74,14 +75,61 @@ static int run_one(const yh_op &o, void *st) {
     }
 }
 
+// Weight-gradient work (backward-weight GEMMs, bias column sums) depends only on dY and on saved
+// activations, never on the rest of the backward chain, and nothing but the optimiser reads its
+// results.  yh_run therefore forks those ops onto a side stream (event fork after the op that produced
+// dY, event join before returning control): the MFMA-bound weight gradients overlap the HBM-bound
+// BatchNorm backward passes and fill the tail rounds of the backward-data GEMMs.
+static int g_overlap = -1;
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork = nullptr, g_join = nullptr;
+
+extern "C" int yh_set_overlap(int enable) {
+    g_overlap = enable ? 1 : 0;
+    return 0;
+}
+
+static int side_ready() {
+    if (g_overlap < 0) {
+        const char *e = getenv("YH_OVERLAP");
+        g_overlap = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g_overlap) return 0;
+    if (!g_side) {
+        if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) {
+            g_side = nullptr;
+            g_overlap = 0;
+            return 0;
+        }
+    }
+    return 1;
+}
+
 extern "C" int yh_run(const yh_op *ops, int n, void *stream, int *failed) {
     YH_REQUIRE(ops || n == 0, "yh_run: null op list");
+    hipStream_t mainst = (hipStream_t)stream;
+    bool forked = false;
     for (int k = 0; k < n; ++k) {
-        int rc = run_one(ops[k], stream);
+        const bool side = (ops[k].kind == YH_OP_CONV_BWD_WEIGHT || ops[k].kind == YH_OP_COLSUM) && side_ready();
+        int rc;
+        if (side) {
+            YH_HIP(hipEventRecord(g_fork, mainst));
+            YH_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+            rc = run_one(ops[k], (void *)g_side);
+            forked = true;
+        } else {
+            rc = run_one(ops[k], stream);
+        }
         if (rc) {
             if (failed) *failed = k;
             return rc;
         }
+    }
+    if (forked) {
+        YH_HIP(hipEventRecord(g_join, g_side));
+        YH_HIP(hipStreamWaitEvent(mainst, g_join, 0));
     }
     return 0;
 }

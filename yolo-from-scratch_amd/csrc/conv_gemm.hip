@@ -15,6 +15,7 @@
 // k values come from one conflict-free ds_read_b128 and feed four MFMAs (the k order inside a
 // chunk is permuted consistently for A and B, which a sum over k does not care about).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct GatherGemm {
     int sy, sx;
     int nTaps, Ktot;
     int accumulate, dense;
+    int nblk_n;
     int tap_dy[9], tap_dx[9], tap_w[9];
 };
 
@@ -51,7 +53,15 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): remap the linear id so that
+    // every XCD walks a contiguous range of tiles with the n-tiles of one m-tile adjacent -- the A
+    // tile re-read by the next n-tile and the 3x3 halo shared with the next m-tile then hit that L2.
+    // Bijective for any grid size (guide section 5, "XCD swizzle must be bijective").
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int mblk = tile / g.nblk_n, nblk = tile - mblk * g.nblk_n;
+    const int m0 = mblk * BM, n0 = nblk * BN;
     if (t < 9) {
         tapt[t] = g.tap_dy[t];
         tapt[9 + t] = g.tap_dx[t];
@@ -233,14 +243,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
                 s += red[(w * BN + t) * 2 + 0];
                 q += red[(w * BN + t) * 2 + 1];
             }
-            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = s;
-            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = q;
+            g.stats[((size_t)mblk * 2 + 0) * g.N + n0 + t] = s;
+            g.stats[((size_t)mblk * 2 + 1) * g.N + n0 + t] = q;
         }
     }
 }
 
 template <int BM, int BN, int WM, int WN, int VEC>
-int launch_cfg(const GatherGemm &g, hipStream_t st) {
+int launch_cfg(GatherGemm g, hipStream_t st) {
     constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 27 * sizeof(int);
     static bool attr_set = false;
     auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC>;
@@ -248,13 +258,27 @@ int launch_cfg(const GatherGemm &g, hipStream_t st) {
         YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN));
+    g.nblk_n = cdiv(g.N, BN);
+    dim3 grid(cdiv(g.M, BM) * g.nblk_n);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("gather_gemm");
     return 0;
 }
 
-constexpr int kBM = 128;
+// Tile choice.  The MFMA pipe is the bound for most layers, so what matters is (a) not padding N
+// (BN = 32/64/128 by channel count) and (b) wave quantisation: a layer with few tiles leaves CUs idle
+// in its last round, so small-M layers take the 64-row tile.
+int pick_bm(int M, int nblk_n) {
+    static const int force = getenv("YH_CONV_BM") ? atoi(getenv("YH_CONV_BM")) : 0;   // tuning knob
+    if (force == 64 || force == 128) return force;
+    const int blocks128 = cdiv(M, 128) * nblk_n;
+    return blocks128 >= 8 * 256 ? 128 : 64;
+}
+
+int stats_bm(int M, int N) {   // rows per BatchNorm partial-sum block = the BM the forward launch will use
+    int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+    return bn == 32 ? 128 : pick_bm(M, cdiv(N, bn));
+}
 
 int launch(const GatherGemm &g, hipStream_t st) {
     YH_REQUIRE(g.M > 0 && g.N > 0 && g.Ktot > 0, "gather_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.Ktot);
@@ -262,17 +286,26 @@ int launch(const GatherGemm &g, hipStream_t st) {
                g.ldw, g.N);
     YH_REQUIRE(((uintptr_t)g.w & 15) == 0, "gather_gemm: weights must be 16-byte aligned");
     const bool vec = (g.Cin % 4 == 0) && (g.ldi % 4 == 0) && (((uintptr_t)g.in & 15) == 0);
-    if (g.N <= 32) return vec ? launch_cfg<kBM, 32, 4, 1, 4>(g, st) : launch_cfg<kBM, 32, 4, 1, 1>(g, st);
-    if (g.N <= 64) return vec ? launch_cfg<kBM, 64, 2, 2, 4>(g, st) : launch_cfg<kBM, 64, 2, 2, 1>(g, st);
-    return vec ? launch_cfg<kBM, 128, 2, 2, 4>(g, st) : launch_cfg<kBM, 128, 2, 2, 1>(g, st);
+    const int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
+    const int bm = bn == 32 ? 128 : pick_bm(g.M, cdiv(g.N, bn));
+#define YH_CFG(BM_, BN_, WM_, WN_) (vec ? launch_cfg<BM_, BN_, WM_, WN_, 4>(g, st) : launch_cfg<BM_, BN_, WM_, WN_, 1>(g, st))
+    if (bm == 128) {
+        if (bn == 32) return YH_CFG(128, 32, 4, 1);
+        if (bn == 64) return YH_CFG(128, 64, 2, 2);
+        return YH_CFG(128, 128, 2, 2);
+    }
+    if (bn == 32) return YH_CFG(128, 32, 4, 1);   // N <= 32 layers always have a huge M
+    if (bn == 64) return YH_CFG(64, 64, 2, 2);
+    return YH_CFG(64, 128, 2, 2);
+#undef YH_CFG
 }
 
 }  // namespace
 
 extern "C" int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s) {
-    (void)Cout;
     int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
-    return cdiv(B * Ho * Wo, kBM);
+    int M = B * Ho * Wo;
+    return cdiv(M, stats_bm(M, Cout));
 }
 
 extern "C" int yh_conv_fwd(const float *x, int ldx, const float *wf, int ldwf, const float *bias, float *y, int ldy,

@@ -14,10 +14,11 @@
 // tiles in registers across the whole range.  Partial slabs go to a workspace [split][tap][ci][co];
 // a second kernel adds the splits in a fixed order and writes OIHW -- deterministic, no atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int P = 32;   // output pixels per segment
+constexpr int PMAX = 40;   // output pixels per segment (even, chosen per layer so rows split evenly)
 
 struct Wgrad {
     const float *x, *dy;
@@ -27,15 +28,19 @@ struct Wgrad {
     int Cin, Cout, k, s, pad;
     int CIT, COT, n_ci_tiles;
     int nseg_row, nseg_total, segs_per_split;
-    int vec_dy;
+    int vec_dy, P;
 };
 
-template <int NT>
+// XL / DL: compile-time upper bounds of the float4 staging loads per thread for the input halo and
+// the dy row, so the loads of the NEXT segment are issued back to back into registers and stay in
+// flight while the MFMAs of the current segment run (register-staged double buffering).
+template <int NT, int XL, int DL>
 __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int KK = g.k * g.k;
+    const int P = g.P;
     const int XW = (P - 1) * g.s + g.k;
     const int CIT = g.CIT, COT = g.COT;
     float *Xs = smem;                          // [k][XW][CIT]
@@ -65,41 +70,65 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
     }
 
+    // fixed staging slots of this thread: slot j handles float4 index t + 256 j
+    const int citq = CIT >> 2, cotq = COT >> 2;
+    const int nx = g.k * XW * citq, nd = P * cotq;
+    int xkh[XL], xcol[XL], xc[XL], dp[DL], dc[DL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        int i = t + 256 * j;
+        int c4 = i % citq, q = i / citq;
+        xcol[j] = q % XW; xkh[j] = q / XW; xc[j] = 4 * c4;
+        if (i >= nx) xkh[j] = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        int i = t + 256 * j;
+        dc[j] = 4 * (i % cotq); dp[j] = i / cotq;
+        if (i >= nd) dp[j] = -1;
+    }
+
     const int seg_begin = blockIdx.x * g.segs_per_split;
     int seg_end = seg_begin + g.segs_per_split;
     if (seg_end > g.nseg_total) seg_end = g.nseg_total;
-    const int citq = CIT >> 2;
 
-    for (int seg = seg_begin; seg < seg_end; ++seg) {
+    f32x4 rx[XL], rd[DL];
+    auto load_seg = [&](int seg) {
         const int sr = seg % g.nseg_row, rowid = seg / g.nseg_row;
         const int ho = rowid % g.Ho, b = rowid / g.Ho;
         const int w0 = sr * P;
         const int pv = (g.Wo - w0) < P ? (g.Wo - w0) : P;
         const int xcols = (pv - 1) * g.s + g.k;
-        __syncthreads();   // previous segment's fragment reads are done
-        // stage input halo rows (zero outside the image, beyond the segment or beyond Cin)
-        for (int i = t; i < g.k * XW * citq; i += 256) {
-            int c4 = i % citq, q = i / citq;
-            int col = q % XW, kh = q / XW;
-            int hi = ho * g.s + kh - g.pad, wi = w0 * g.s - g.pad + col;
-            int c = ci0 + 4 * c4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (col < xcols && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi && c < g.Cin)
-                v = *(const f32x4 *)(g.x + ((size_t)(b * g.Hi + hi) * g.Wi + wi) * g.ldx + c);
-            *(f32x4 *)(Xs + (kh * XW + col) * CIT + 4 * c4) = v;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            int hi = ho * g.s + xkh[j] - g.pad, wi = w0 * g.s - g.pad + xcol[j];
+            int c = ci0 + xc[j];
+            bool ok = xkh[j] >= 0 && xcol[j] < xcols && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi && c < g.Cin;
+            rx[j] = ok ? *(const f32x4 *)(g.x + ((size_t)(b * g.Hi + hi) * g.Wi + wi) * g.ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // stage the dy row segment
         if (g.vec_dy) {
-            const int cotq = COT >> 2;
-            for (int i = t; i < P * cotq; i += 256) {
-                int c4 = i % cotq, p = i / cotq;
-                int c = co0 + 4 * c4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (p < pv && c < g.Cout)
-                    v = *(const f32x4 *)(g.dy + ((size_t)(b * g.Ho + ho) * g.Wo + w0 + p) * g.lddy + c);
-                *(f32x4 *)(Ds + p * COT + 4 * c4) = v;
+#pragma unroll
+            for (int j = 0; j < DL; ++j) {
+                int c = co0 + dc[j];
+                bool ok = dp[j] >= 0 && dp[j] < pv && c < g.Cout;
+                rd[j] = ok ? *(const f32x4 *)(g.dy + ((size_t)(b * g.Ho + ho) * g.Wo + w0 + dp[j]) * g.lddy + c)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        } else {
+        }
+    };
+    auto store_seg = [&](int seg) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j)
+            if (xkh[j] >= 0) *(f32x4 *)(Xs + (xkh[j] * XW + xcol[j]) * CIT + xc[j]) = rx[j];
+        if (g.vec_dy) {
+#pragma unroll
+            for (int j = 0; j < DL; ++j)
+                if (dp[j] >= 0) *(f32x4 *)(Ds + dp[j] * COT + dc[j]) = rd[j];
+        } else {   // dy rows that are not 16-byte addressable (head outputs: 18 or 255 channels): scalar staging
+            const int sr = seg % g.nseg_row, rowid = seg / g.nseg_row;
+            const int ho = rowid % g.Ho, b = rowid / g.Ho;
+            const int w0 = sr * P;
+            const int pv = (g.Wo - w0) < P ? (g.Wo - w0) : P;
             for (int i = t; i < P * COT; i += 256) {
                 int c = i % COT, p = i / COT;
                 float v = 0.f;
@@ -107,18 +136,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
                 Ds[p * COT + c] = v;
             }
         }
+    };
+
+    if (seg_begin < seg_end) load_seg(seg_begin);
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        const int w0 = (seg % g.nseg_row) * P;
+        const int pv = (g.Wo - w0) < P ? (g.Wo - w0) : P;
+        __syncthreads();   // previous segment's fragment reads are done
+        store_seg(seg);
         __syncthreads();
+        if (seg + 1 < seg_end) load_seg(seg + 1);
         const int npairs = (pv + 1) >> 1;
+#pragma unroll 2
         for (int pp = 0; pp < npairs; ++pp) {
             const int p = 2 * pp + lh;
             const int xo = p * g.s * CIT, dofs = p * COT;
+            // branch-free: all fragment reads are issued before the MFMAs; tiles past the slab (at most
+            // one per wave) multiply zeros / unused columns and are never stored
+            float av[NT], bv[NT];
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                if (!tvalid[u]) continue;
-                float a = avalid[u] ? Xs[aoff[u] + xo] : 0.f;
-                float bb = Ds[boff[u] + dofs];
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[u], 0, 0, 0);
+                av[u] = Xs[aoff[u] + xo];
+                bv[u] = Ds[boff[u] + dofs];
             }
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(avalid[u] ? av[u] : 0.f, bv[u], acc[u], 0, 0, 0);
         }
     }
 
@@ -142,17 +185,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
     }
 }
 
-// dw[co][ci][tap] (ci < cin_real) = sum_split ws[split][tap][ci][co], splits added in index order
-__global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int nsplit, int KK, int Cin,
-                                    int cin_real, int Cout) {
+// dw[co][ci][tap] (ci < cin_real) = sum_split ws[split][tap][ci][co].  A workgroup owns 16 consecutive
+// elements; 16 split-lanes each add every 16th split, then the lanes are combined in lane order:
+// the summation order is fixed, so the result is bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw,
+                                                           int nsplit, int KK, int Cin, int cin_real, int Cout) {
+    __shared__ float red[16][17];
     const int n = KK * Cin * Cout;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (i < n)
+        for (int k = sl; k < nsplit; k += 16) s += ws[(size_t)k * n + i];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][e];
         int co = i % Cout, q = i / Cout;
         int ci = q % Cin, tap = q / Cin;
-        if (ci >= cin_real) continue;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * n + i];
-        dw[((size_t)co * cin_real + ci) * KK + tap] = s;
+        if (ci < cin_real) dw[((size_t)co * cin_real + ci) * KK + tap] = tot;
     }
 }
 
@@ -178,7 +231,8 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     // slab shape: keep <= 36 tiles (9 per wave) and LDS modest
     if (k == 1) { g.CIT = Cin >= 128 ? 128 : Cin; g.COT = Cout >= 128 ? 128 : (Cout + 3) / 4 * 4; }
     else {
-        g.CIT = (s == 2) ? (Cin >= 32 ? 32 : Cin) : (Cin >= 64 ? 64 : Cin);
+        static const int cit3 = getenv("YH_WGRAD_CIT3") ? atoi(getenv("YH_WGRAD_CIT3")) : 32;   // tuning knob
+        g.CIT = (s == 2) ? (Cin >= 32 ? 32 : Cin) : (Cin >= cit3 ? cit3 : Cin);
         g.COT = Cout >= 64 ? 64 : (Cout + 3) / 4 * 4;
     }
     if (g.CIT % 4) return YH_E_UNSUPPORTED;
@@ -186,10 +240,24 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     pl.ntiles = g.n_ci_tiles * cdiv(Cout, g.COT);
     int RT = cdiv(k * k * g.CIT, 32), OT = cdiv(g.COT, 32);
     pl.NT = cdiv(RT * OT, 4);
+    // segment length: the candidate with the least padded work that fits the staging-register budget
+    {
+        const int cand[4] = {40, 32, 20, 16};
+        int best = 32, best_work = 1 << 30;
+        for (int c : cand) {
+            int xw = (c - 1) * s + k;
+            if (cdiv(k * xw * (g.CIT / 4), 256) > 7 || (cdiv(k * xw * (g.CIT / 4), 256) > 4 && cdiv(c * (g.COT / 4), 256) > 2)) continue;
+            int work = cdiv(g.Wo, c) * c;
+            if (work < best_work) { best_work = work; best = c; }
+        }
+        g.P = best;
+    }
+    const int P = g.P;
     g.nseg_row = cdiv(g.Wo, P);
     g.nseg_total = g.B * g.Ho * g.nseg_row;
     int64_t wsize = (int64_t)k * k * Cin * Cout;
-    int want = 1536 / pl.ntiles;                      // ~6 workgroups per CU in total
+    static const int target = getenv("YH_WGRAD_BLOCKS") ? atoi(getenv("YH_WGRAD_BLOCKS")) : 512;   // tuning knob
+    int want = target / pl.ntiles;                    // ~2 workgroups per CU in total
     if (want < 1) want = 1;
     int64_t cap = (48ll << 20) / wsize;               // <= 192 MiB of partials
     if (cap < 1) cap = 1;
@@ -202,10 +270,10 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     return 0;
 }
 
-template <int NT>
-int launch_wgrad(const Plan &pl, hipStream_t st) {
+template <int NT, int XL, int DL>
+int launch_wgrad_cfg(const Plan &pl, hipStream_t st) {
     static size_t attr = 0;
-    auto kern = wgrad_kernel<NT>;
+    auto kern = wgrad_kernel<NT, XL, DL>;
     if (pl.smem > attr) {
         YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
         attr = pl.smem;
@@ -213,6 +281,18 @@ int launch_wgrad(const Plan &pl, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.ntiles), dim3(256), pl.smem, st, pl.g);
     YH_CHECK_LAUNCH("wgrad");
     return 0;
+}
+
+template <int NT>
+int launch_wgrad(const Plan &pl, hipStream_t st) {
+    const Wgrad &g = pl.g;
+    const int XW = (g.P - 1) * g.s + g.k;
+    const int xl = cdiv(g.k * XW * (g.CIT / 4), 256), dl = cdiv(g.P * (g.COT / 4), 256);
+    if (xl <= 2 && dl <= 2) return launch_wgrad_cfg<NT, 2, 2>(pl, st);
+    if (xl <= 4 && dl <= 4) return launch_wgrad_cfg<NT, 4, 4>(pl, st);
+    if (xl <= 7 && dl <= 2) return launch_wgrad_cfg<NT, 7, 2>(pl, st);
+    yh_set_error("conv_bwd_weight: staging shape (%d, %d) unsupported", xl, dl);
+    return YH_E_UNSUPPORTED;
 }
 
 }  // namespace
@@ -251,9 +331,7 @@ extern "C" int yh_conv_bwd_weight(const float *x, int ldx, const float *dy, int 
     }
     if (rc) return rc;
     int n = k * k * Cin * Cout;
-    int blocks = cdiv(n, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, pl.nsplit, k * k, Cin, cin_real, Cout);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, ws, dw, pl.nsplit, k * k, Cin, cin_real, Cout);
     YH_CHECK_LAUNCH("wgrad_reduce");
     return 0;
 }

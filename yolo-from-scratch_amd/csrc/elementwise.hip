@@ -76,11 +76,11 @@ __global__ void colsum_stage1(const float *__restrict__ x, int ldx, int64_t M, i
     }
 }
 __global__ void colsum_stage2(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;            // one wave per channel, lanes stride the partials, fixed butterfly order
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * C + c];
-    out[c] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -88,7 +88,7 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nblk, int C, f
 __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, double count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
-                                   float *__restrict__ coef, int C) {
+                                   float *__restrict__ coef, int C, int64_t *__restrict__ nbt) {
     __shared__ double rs[4], rq[4];
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
@@ -115,6 +115,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, dou
             rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
             rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
         }
+        if (nbt && c == 0) *nbt += 1;
     }
 }
 
@@ -388,17 +389,17 @@ extern "C" int yh_colsum(const float *x, int ldx, int64_t M, int C, float *out, 
     int64_t rows = cdiv64(M, nblk);
     hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
     YH_CHECK_LAUNCH("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out);
+    hipLaunchKernelGGL(colsum_stage2, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out);
     YH_CHECK_LAUNCH("colsum_stage2");
     return 0;
 }
 
 extern "C" int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
                               float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
-                              void *stream) {
+                              int64_t *num_batches_tracked, void *stream) {
     YH_REQUIRE(partials && gamma && beta && coef && nblk > 0 && count > 0 && C > 0, "bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, (double)count,
-                       gamma, beta, running_mean, running_var, momentum, eps, coef, C);
+                       gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked);
     YH_CHECK_LAUNCH("bn_finalize");
     return 0;
 }

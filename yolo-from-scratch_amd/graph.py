@@ -209,10 +209,9 @@ class Plan:
                         mom = r.bn.momentum if r.bn.momentum is not None else 0.1
                         fwd.append(_op(L.OP_BN_FINALIZE,
                                        p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
-                                          r.bn.running_var if track else None, r.coef],
+                                          r.bn.running_var if track else None, r.coef,
+                                          r.bn.num_batches_tracked if track else None],
                                        i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M]))
-                        if track and r.bn.num_batches_tracked is not None:
-                            fwd.append(_op(L.OP_ADD_INT64, p=[r.bn.num_batches_tracked], l=[1]))
                     fwd.append(_op(L.OP_BN_SILU_FWD,
                                    p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
                                    i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
