@@ -34,6 +34,7 @@ struct GatherGemm {
     int nTaps, Ktot;
     int accumulate, dense;
     int nblk_n;
+    unsigned cin_magic;   // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, magic) for k < 2^16
     int tap_dy[9], tap_dx[9], tap_w[9];
 };
 
@@ -68,20 +69,21 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
         tapt[18 + t] = g.tap_w[t];
     }
 
-    // per-thread A rows: r = (t>>3) + 32*i, float4 column kq = t&7
+    // per-thread A rows: r = (t>>3) + 32*i, float4 column kq = t&7.  roff = element offset of the
+    // row's centre pixel; a tap adds the block-uniform-or-per-thread delta (dy*Wi + dx)*ldi.
     const int kq = t & 7;
-    int rbase[AROWS], riy[AROWS], rix[AROWS];
+    int roff[AROWS], riy[AROWS], rix[AROWS];
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
         int m = m0 + (t >> 3) + 32 * i;
         if (m < g.M) {
             int x = m % g.Xo, q = m / g.Xo;
             int y = q % g.Yo, b = q / g.Yo;
-            rbase[i] = b * g.Hi * g.Wi;
             riy[i] = y * g.sy;
             rix[i] = x * g.sx;
+            roff[i] = ((b * g.Hi + riy[i]) * g.Wi + rix[i]) * g.ldi;
         } else {
-            rbase[i] = 0;
+            roff[i] = 0;
             riy[i] = -(1 << 20);
             rix[i] = 0;
         }
@@ -93,14 +95,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
         const int k = c * BK + 4 * kq;
         if (VEC == 4) {
             if (k < g.Ktot) {
-                int tap = k / g.Cin, ci = k - tap * g.Cin;
+                int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
                 int dy = tapt[tap], dx = tapt[9 + tap];
+                int toff = (dy * g.Wi + dx) * g.ldi + ci;
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
-                    int iy = riy[i] + dy, ix = rix[i] + dx;
-                    bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                    ra[i] = ok ? *(const f32x4 *)(g.in + ((size_t)(rbase[i] + iy * g.Wi + ix) * g.ldi + ci))
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
+                    bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                    ra[i] = ok ? *(const f32x4 *)(g.in + (roff[i] + toff)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             } else {
 #pragma unroll
@@ -113,13 +114,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
             for (int e = 0; e < 4; ++e) {
                 int ke = k + e;
                 if (ke < g.Ktot) {
-                    int tap = ke / g.Cin, ci = ke - tap * g.Cin;
+                    int tap = (int)__umulhi((unsigned)ke, g.cin_magic), ci = ke - tap * g.Cin;
                     int dy = tapt[tap], dx = tapt[9 + tap];
+                    int toff = (dy * g.Wi + dx) * g.ldi + ci;
 #pragma unroll
                     for (int i = 0; i < AROWS; ++i) {
-                        int iy = riy[i] + dy, ix = rix[i] + dx;
-                        bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-                        if (ok) ra[i][e] = g.in[(size_t)(rbase[i] + iy * g.Wi + ix) * g.ldi + ci];
+                        bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                        if (ok) ra[i][e] = g.in[roff[i] + toff];
                     }
                 }
             }
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
             int kr = c * BK + t / BQ + p * BROWS;
             int n = n0 + 4 * (t % BQ);
             if (kr < g.Ktot && n < g.ldw) {
-                int tap = kr / g.Cin, ci = kr - tap * g.Cin;
-                rb[p] = *(const f32x4 *)(g.w + (size_t)(tapt[18 + tap] * g.Cin + ci) * g.ldw + n);
+                int tap = (int)__umulhi((unsigned)kr, g.cin_magic), ci = kr - tap * g.Cin;
+                rb[p] = *(const f32x4 *)(g.w + ((tapt[18 + tap] * g.Cin + ci) * g.ldw + n));
             } else {
                 rb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -259,6 +260,7 @@ int launch_cfg(GatherGemm g, hipStream_t st) {
         attr_set = true;
     }
     g.nblk_n = cdiv(g.N, BN);
+    g.cin_magic = (unsigned)((1ull << 32) / (unsigned)g.Cin) + 1u;
     dim3 grid(cdiv(g.M, BM) * g.nblk_n);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("gather_gemm");
@@ -285,6 +287,8 @@ int launch(const GatherGemm &g, hipStream_t st) {
     YH_REQUIRE(g.ldw % 4 == 0 && g.ldw >= g.N, "gather_gemm: weight row stride %d must be a multiple of 4 and >= N=%d",
                g.ldw, g.N);
     YH_REQUIRE(((uintptr_t)g.w & 15) == 0, "gather_gemm: weights must be 16-byte aligned");
+    YH_REQUIRE(g.Ktot < 65536 && (int64_t)g.B * g.Hi * g.Wi * g.ldi < (1ll << 31) && (int64_t)g.Ktot * g.ldw < (1ll << 31),
+               "gather_gemm: problem exceeds the 32-bit element-offset range");
     const bool vec = (g.Cin % 4 == 0) && (g.ldi % 4 == 0) && (((uintptr_t)g.in & 15) == 0);
     const int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
     const int bm = bn == 32 ? 128 : pick_bm(g.M, cdiv(g.N, bn));

@@ -25,6 +25,50 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+class GradBuckets:
+    """Data-parallel gradient exchange over a flat gradient buffer (torch.distributed only: RCCL on the
+    GPUs, gloo in the CPU tests).  The buffer is cut into contiguous buckets (parameter registration
+    order); each bucket knows after how many backward ops its gradients are final, so its all-reduce
+    (SUM; the 1/world factor is folded into the clip+Adam kernel) can be issued while the rest of the
+    backward still runs.  `plan_segments` returns [(n_ops_done, (begin, end) | None), ...]."""
+
+    def __init__(self, flat_g: torch.Tensor, process_group=None, n_buckets: int = 4):
+        self.flat_g, self.pg, self.n_buckets = flat_g, process_group, max(1, n_buckets)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._works = []
+
+    def plan_segments(self, spans, ready, n_ops):
+        """spans: [(offset, padded_numel)] per parameter in registration order; ready: op count after
+        which each parameter's gradient is final; n_ops: length of the backward op list."""
+        if self.world == 1:
+            return [(n_ops, None)]
+        total = self.flat_g.numel()
+        target = total / self.n_buckets
+        buckets, start, rdy = [], 0, 0
+        for (off, n), r in zip(spans, ready):
+            end = off + n
+            rdy = max(rdy, r)
+            if end - start >= target and len(buckets) < self.n_buckets - 1:
+                buckets.append((rdy, (start, end)))
+                start, rdy = end, 0
+        if start < total:
+            buckets.append((rdy, (start, total)))
+        buckets.sort(key=lambda b: b[0])          # earliest-complete first (heads, neck, then backbone)
+        if buckets[-1][0] < n_ops:
+            buckets.append((n_ops, None))
+        return buckets
+
+    def launch(self, rng):
+        if self.world > 1 and rng is not None:
+            self._works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.pg,
+                                               async_op=True))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
 class HipTrainer:
     """Owns the flat parameter / gradient / Adam-state buffers of a YOLO model and runs fused steps."""
 
@@ -58,39 +102,18 @@ class HipTrainer:
         self.norm_ws = torch.empty(int(L.lib().yh_sqnorm_ws(n)) + 2, device=self.device, dtype=torch.float64)
         self.loss_out = torch.zeros(13, device=self.device, dtype=torch.float32)
         self._loss_ws = None
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        self.n_buckets = max(1, n_buckets)
+        self.buckets = GradBuckets(self.flat_g, process_group, n_buckets)
+        self.pg, self.world = process_group, self.buckets.world
         self._segments = None
         self._params = params
         if self.world > 1:
             dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                            group=process_group)      # identical replicas
 
-    # ---- data-parallel bucketing ----------------------------------------------------------------
     def _plan_segments(self, plan):
-        """Split the flat gradient buffer into contiguous buckets (registration order) and find, for
-        each, the backward-op index after which all of its gradients are final."""
-        n_ops = plan.bwd_ops[1]
-        if self.world == 1:
-            return [(n_ops, None)]
-        total = self.flat_g.numel()
-        target = total / self.n_buckets
-        buckets, start, ready = [], 0, 0
-        for p in self._params:
-            off, numel = self.offsets[id(p)]
-            end = off + (numel + 3) // 4 * 4
-            ready = max(ready, plan.grad_ready[id(p)])
-            if end - start >= target and len(buckets) < self.n_buckets - 1:
-                buckets.append((ready, (start, end)))
-                start, ready = end, 0
-        if start < total:
-            buckets.append((ready, (start, total)))
-        buckets.sort(key=lambda b: b[0])          # earliest-complete bucket first (heads, then neck, then backbone)
-        segs = [(rdy, rng) for rdy, rng in buckets]
-        if segs[-1][0] < n_ops:
-            segs.append((n_ops, None))
-        return segs
+        spans = [(self.offsets[id(p)][0], (self.offsets[id(p)][1] + 3) // 4 * 4) for p in self._params]
+        ready = [plan.grad_ready[id(p)] for p in self._params]
+        return self.buckets.plan_segments(spans, ready, plan.bwd_ops[1])
 
     # ---- one step -------------------------------------------------------------------------------
     def step(self, imgs: torch.Tensor, targets: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -113,14 +136,12 @@ class HipTrainer:
         run_loss_kernel([v.buf.data for v in heads], [t.contiguous() for t in targets], [v.buf.grad for v in heads],
                         _anchors18(model.anchors), [v.H for v in heads], plan.B, nc, None, None, self.loss_out,
                         self._loss_ws, st)
-        works, begin = [], 0
+        begin = 0
         for end, rng in self._segments[1]:
-            plan.run_backward(st, begin, end)
+            plan.run_backward(st, begin, end)       # yh_run joins its side stream before returning
             begin = end
-            if rng is not None and self.world > 1:
-                works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        for w in works:
-            w.wait()
+            self.buckets.launch(rng)                # RCCL runs on its own stream, under the next segment
+        self.buckets.wait()
         self.apply_update()
         return self.loss_out
 
