@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -107,8 +108,15 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            if local >= ndev:
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = local % max(ndev, 1)
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

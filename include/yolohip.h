@@ -39,6 +39,9 @@ int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, in
  * either destination may be NULL.  Cin_pad >= Cin rows beyond Cin are zero (stem: 3 -> 4). */
 int yh_pack_weights(const float *oihw, float *wf, float *wb, int Cout, int Cin, int k, int cin_pad, int ldwf,
                     int ldwb, void *stream);
+/* The same for n_layers convolutions in ONE launch.  `table` is a DEVICE array of n_layers records of
+ * 56 bytes: { const float *oihw; float *wf; float *wb; int32 Cout, Cin, k*k, cin_pad, ldwf, ldwb, 0, 0 }. */
+int yh_pack_weights_multi(const void *table, int n_layers, void *stream);
 
 /* ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) ---------------------------------- */
 /* Forward: y = conv(x, w) (+ bias); square kernel k in {1,3}, stride s in {1,2}, pad k/2.
@@ -176,7 +179,7 @@ enum {
     YH_OP_NCHW_TO_NHWC = 1, YH_OP_NHWC_TO_NCHW, YH_OP_PACK_WEIGHTS, YH_OP_CONV_FWD, YH_OP_CONV_BWD_DATA,
     YH_OP_CONV_BWD_WEIGHT, YH_OP_COLSUM, YH_OP_BN_FINALIZE, YH_OP_BN_EVAL_COEF, YH_OP_BN_SILU_FWD,
     YH_OP_BN_SILU_BWD_REDUCE, YH_OP_BN_SILU_BWD_APPLY, YH_OP_MAXPOOL5_FWD, YH_OP_MAXPOOL5_BWD, YH_OP_MEMSET,
-    YH_OP_ADD_INT64
+    YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Backward-weight and column-sum ops are forked onto an

@@ -26,7 +26,7 @@ class YhOp(C.Structure):
 # op kinds, same order as the enum in yolohip.h
 (OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_PACK_WEIGHTS, OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT,
  OP_COLSUM, OP_BN_FINALIZE, OP_BN_EVAL_COEF, OP_BN_SILU_FWD, OP_BN_SILU_BWD_REDUCE, OP_BN_SILU_BWD_APPLY,
- OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64) = range(1, 17)
+ OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI) = range(1, 18)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -39,6 +39,7 @@ _SIGS = {
     "yh_nchw_to_nhwc": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_nhwc_to_nchw": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_weights": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_pack_weights_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),

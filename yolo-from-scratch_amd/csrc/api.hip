@@ -69,6 +69,8 @@ static int run_one(const yh_op &o, void *st) {
             return yh_memset(p[0], i[0], o.l[0], st);
         case YH_OP_ADD_INT64:
             return yh_add_int64((int64_t *)p[0], o.l[0], st);
+        case YH_OP_PACK_WEIGHTS_MULTI:
+            return yh_pack_weights_multi(p[0], i[0], st);
         default:
             yh_set_error("yh_run: unknown op kind %d", o.kind);
             return YH_E_BADARG;

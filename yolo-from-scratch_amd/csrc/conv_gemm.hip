@@ -273,8 +273,11 @@ int launch_cfg(GatherGemm g, hipStream_t st) {
 int pick_bm(int M, int nblk_n) {
     static const int force = getenv("YH_CONV_BM") ? atoi(getenv("YH_CONV_BM")) : 0;   // tuning knob
     if (force == 64 || force == 128) return force;
+    // measured on MI355X (tools/layer_bench.py): 64-row tiles win whenever the 128-row grid is small,
+    // except when it fills the chip exactly once at two workgroups per CU (256 < blocks <= 512)
     const int blocks128 = cdiv(M, 128) * nblk_n;
-    return blocks128 >= 8 * 256 ? 128 : 64;
+    if (blocks128 >= 8 * 256) return 128;
+    return (blocks128 > 256 && blocks128 <= 512) ? 128 : 64;
 }
 
 int stats_bm(int M, int N) {   // rows per BatchNorm partial-sum block = the BM the forward launch will use

@@ -49,8 +49,54 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, float *__restri
     }
 }
 
+// all layers of a plan in one launch: blockIdx.y = layer, descriptor table in device memory
+struct PackDesc {
+    const float *w;
+    float *wf, *wb;
+    int Cout, Cin, kk, cin_pad, ldwf, ldwb, pad0, pad1;
+};
+__global__ void pack_weights_multi_kernel(const PackDesc *__restrict__ tab) {
+    const PackDesc d = tab[blockIdx.y];
+    const int nf = d.wf ? d.kk * d.cin_pad * d.ldwf : 0;
+    const int nb = d.wb ? d.kk * d.Cout * d.ldwb : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+        if (i < nf) {
+            int n = i % d.ldwf, q = i / d.ldwf;
+            int ci = q % d.cin_pad, t = q / d.cin_pad;
+            d.wf[i] = (n < d.Cout && ci < d.Cin) ? d.w[((size_t)n * d.Cin + ci) * d.kk + t] : 0.f;
+        } else {
+            int j = i - nf;
+            int ci = j % d.ldwb, q = j / d.ldwb;
+            int co = q % d.Cout, t = q / d.Cout;
+            d.wb[j] = (ci < d.Cin) ? d.w[((size_t)co * d.Cin + ci) * d.kk + t] : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column sums: stage 1 -> partial[blk][C], stage 2 -> out[C]
+// vector path (C % 4 == 0, 16-byte addressable rows): float4 columns x row groups, like the BN reductions
+__global__ void colsum_stage1_vec(const float *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
+                                  int64_t rows_per_blk) {
+    __shared__ float red[256 * 4];
+    const int t = threadIdx.x, cq = C >> 2;
+    const int rg = 256 / cq, c4 = t % cq, r_in = t / cq;
+    int64_t r0 = blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk;
+    if (r1 > M) r1 = M;
+    f32x4 s = {0, 0, 0, 0};
+    if (r_in < rg)
+        for (int64_t r = r0 + r_in; r < r1; r += rg) s += *(const f32x4 *)(x + r * ldx + 4 * c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[t * 4 + e] = s[e];
+    __syncthreads();
+    if (t < cq) {
+        f32x4 a = {0, 0, 0, 0};
+        for (int k = 0; k < rg; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += red[(k * cq + t) * 4 + e];
+        *(f32x4 *)(part + (size_t)blockIdx.x * C + 4 * t) = a;
+    }
+}
 __global__ void colsum_stage1(const float *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
                               int64_t rows_per_blk) {
     __shared__ float red[256];
@@ -378,6 +424,15 @@ extern "C" int yh_pack_weights(const float *oihw, float *wf, float *wb, int Cout
     return 0;
 }
 
+extern "C" int yh_pack_weights_multi(const void *table, int n_layers, void *stream) {
+    YH_REQUIRE(table && n_layers > 0, "pack_weights_multi: bad argument");
+    static_assert(sizeof(PackDesc) == 56, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(32, n_layers), dim3(256), 0, (hipStream_t)stream,
+                       (const PackDesc *)table);
+    YH_CHECK_LAUNCH("pack_weights_multi");
+    return 0;
+}
+
 static int colsum_blocks(int64_t M) {
     int64_t b = cdiv64(M, 512);
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
@@ -387,7 +442,10 @@ extern "C" int yh_colsum(const float *x, int ldx, int64_t M, int C, float *out, 
     YH_REQUIRE(x && out && ws && M > 0 && C > 0 && ldx >= C, "colsum: bad argument");
     int nblk = colsum_blocks(M);
     int64_t rows = cdiv64(M, nblk);
-    hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
+    if (C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(colsum_stage1_vec, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
+    else
+        hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
     YH_CHECK_LAUNCH("colsum_stage1");
     hipLaunchKernelGGL(colsum_stage2, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out);
     YH_CHECK_LAUNCH("colsum_stage2");

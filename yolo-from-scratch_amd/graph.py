@@ -176,6 +176,7 @@ class Plan:
         f32 = dict(device=dev, dtype=torch.float32)
         fwd: List[L.YhOp] = []
         keep: List[torch.Tensor] = []          # tensors referenced only through raw pointers
+        packs: List[tuple] = []                # one descriptor per conv for the single pack launch
         for r in self.recs:
             if isinstance(r, ConvRec):
                 kk = r.k * r.k
@@ -183,8 +184,8 @@ class Plan:
                 r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
                 r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
-                fwd.append(_op(L.OP_PACK_WEIGHTS, p=[r.weight, r.wf, r.wb],
-                               i=[r.cout, r.weight.shape[1], r.k, r.cin, r.ldwf, r.ldwb]))
+                packs.append((r.weight.data_ptr(), r.wf.data_ptr(), r.wb.data_ptr() if r.wb is not None else 0,
+                              r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
                 if r.bn is not None:
                     r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32)
                     r.coef = torch.empty(4 * r.cout, **f32)
@@ -220,6 +221,11 @@ class Plan:
                 r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
                 fwd.append(_op(L.OP_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
                                i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C]))
+        if packs:   # every conv's OIHW -> packed copies in ONE launch at the head of the forward list
+            import struct
+            blob = b"".join(struct.pack("<QQQiiiiiiii", *d, 0, 0) for d in packs)
+            self.pack_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            fwd.insert(0, _op(L.OP_PACK_WEIGHTS_MULTI, p=[self.pack_table], i=[len(packs)]))
         self.fwd_ops = _pack(fwd)
         self.bwd_ops = _pack(self._lower_backward(grad_of, keep)) if self.training else None
         self._keep = keep
