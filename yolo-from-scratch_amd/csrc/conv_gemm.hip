@@ -35,11 +35,25 @@ struct GatherGemm {
     int accumulate, dense;
     int nblk_n;
     unsigned cin_magic;   // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, magic) for k < 2^16
+    unsigned xo_magic, yo_magic;   // exact division of a pixel index < 2^31 by Xo / Yo (see fast_div)
+    int xo_shift, yo_shift;
     int tap_dy[9], tap_dx[9], tap_w[9];
 };
 
-template <int BM, int BN, int WM, int WN, int VEC>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
+// Up to four output-parity classes of a stride-2 backward-data pass share one launch (blockIdx.y).
+struct GatherGemmSet {
+    GatherGemm c[4];
+};
+
+// floor(n / d) for 0 <= n < 2^31: magic = ceil(2^(31+l) / d) with l = ceil(log2 d) fits 32 bits and
+// (n * magic) >> (31 + l) is exact (Granlund-Montgomery); stored shift = l - 1, shift < 0 means d == 1.
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
+    return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
+}
+
+template <int BM, int BN, int WM, int WN, int VEC, int NCLS>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs) {
+    const GatherGemm &g = gs.c[NCLS == 1 ? 0 : blockIdx.y];
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AROWS = BM / 32;
     constexpr int BQ = BN / 4;
@@ -58,7 +72,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
     // every XCD walks a contiguous range of tiles with the n-tiles of one m-tile adjacent -- the A
     // tile re-read by the next n-tile and the 3x3 halo shared with the next m-tile then hit that L2.
     // Bijective for any grid size (guide section 5, "XCD swizzle must be bijective").
-    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int nwg = ((g.M + BM - 1) / BM) * g.nblk_n, orig = blockIdx.x;
+    if (orig >= nwg) return;   // classes of one launch have slightly different tile counts
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int mblk = tile / g.nblk_n, nblk = tile - mblk * g.nblk_n;
@@ -77,8 +92,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
     for (int i = 0; i < AROWS; ++i) {
         int m = m0 + (t >> 3) + 32 * i;
         if (m < g.M) {
-            int x = m % g.Xo, q = m / g.Xo;
-            int y = q % g.Yo, b = q / g.Yo;
+            int q = fast_div(m, g.xo_magic, g.xo_shift), x = m - q * g.Xo;
+            int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
             riy[i] = y * g.sy;
             rix[i] = x * g.sx;
             roff[i] = ((b * g.Hi + riy[i]) * g.Wi + rix[i]) * g.ldi;
@@ -206,8 +221,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
             if (g.dense) {
                 opix = (size_t)m;
             } else {
-                int x = m % g.Xo, q = m / g.Xo;
-                int y = q % g.Yo, b = q / g.Yo;
+                int q = fast_div(m, g.xo_magic, g.xo_shift), x = m - q * g.Xo;
+                int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
                 opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
             }
             float *orow = g.out + opix * g.ldo;
@@ -250,19 +265,31 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemm g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int VEC>
-int launch_cfg(GatherGemm g, hipStream_t st) {
+void set_magic(unsigned d, unsigned &magic, int &shift) {
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    magic = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    shift = l - 1;
+}
+
+template <int BM, int BN, int WM, int WN, int VEC, int NCLS>
+int launch_cfg(GatherGemmSet gs, hipStream_t st) {
     constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 27 * sizeof(int);
     static bool attr_set = false;
-    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC>;
+    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC, NCLS>;
     if (!attr_set) {
         YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    g.nblk_n = cdiv(g.N, BN);
-    g.cin_magic = (unsigned)((1ull << 32) / (unsigned)g.Cin) + 1u;
-    dim3 grid(cdiv(g.M, BM) * g.nblk_n);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
+    int maxblk = 0;
+    for (int c = 0; c < NCLS; ++c) {
+        GatherGemm &g = gs.c[c];
+        g.nblk_n = cdiv(g.N, BN);
+        g.cin_magic = (unsigned)((1ull << 32) / (unsigned)g.Cin) + 1u;
+        int blk = cdiv(g.M, BM) * g.nblk_n;
+        if (blk > maxblk) maxblk = blk;
+    }
+    hipLaunchKernelGGL(kern, dim3(maxblk, NCLS), dim3(256), smem, st, gs);
     YH_CHECK_LAUNCH("gather_gemm");
     return 0;
 }
@@ -285,26 +312,41 @@ int stats_bm(int M, int N) {   // rows per BatchNorm partial-sum block = the BM 
     return bn == 32 ? 128 : pick_bm(M, cdiv(N, bn));
 }
 
-int launch(const GatherGemm &g, hipStream_t st) {
-    YH_REQUIRE(g.M > 0 && g.N > 0 && g.Ktot > 0, "gather_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.Ktot);
-    YH_REQUIRE(g.ldw % 4 == 0 && g.ldw >= g.N, "gather_gemm: weight row stride %d must be a multiple of 4 and >= N=%d",
-               g.ldw, g.N);
-    YH_REQUIRE(((uintptr_t)g.w & 15) == 0, "gather_gemm: weights must be 16-byte aligned");
-    YH_REQUIRE(g.Ktot < 65536 && (int64_t)g.B * g.Hi * g.Wi * g.ldi < (1ll << 31) && (int64_t)g.Ktot * g.ldw < (1ll << 31),
-               "gather_gemm: problem exceeds the 32-bit element-offset range");
+template <int NCLS>
+int launch_set(GatherGemmSet &gs, hipStream_t st) {
+    for (int c = 0; c < NCLS; ++c) {
+        GatherGemm &g = gs.c[c];
+        YH_REQUIRE(g.M > 0 && g.N > 0 && g.Ktot > 0, "gather_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.Ktot);
+        YH_REQUIRE(g.ldw % 4 == 0 && g.ldw >= g.N, "gather_gemm: weight row stride %d must be a multiple of 4 and >= N=%d",
+                   g.ldw, g.N);
+        YH_REQUIRE(((uintptr_t)g.w & 15) == 0, "gather_gemm: weights must be 16-byte aligned");
+        YH_REQUIRE(g.Ktot < 65536 && (int64_t)g.B * g.Hi * g.Wi * g.ldi < (1ll << 31) && (int64_t)g.Ktot * g.ldw < (1ll << 31),
+                   "gather_gemm: problem exceeds the 32-bit element-offset range");
+        set_magic((unsigned)g.Xo, g.xo_magic, g.xo_shift);
+        set_magic((unsigned)g.Yo, g.yo_magic, g.yo_shift);
+    }
+    const GatherGemm &g = gs.c[0];
     const bool vec = (g.Cin % 4 == 0) && (g.ldi % 4 == 0) && (((uintptr_t)g.in & 15) == 0);
     const int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
-    const int bm = bn == 32 ? 128 : pick_bm(g.M, cdiv(g.N, bn));
-#define YH_CFG(BM_, BN_, WM_, WN_) (vec ? launch_cfg<BM_, BN_, WM_, WN_, 4>(g, st) : launch_cfg<BM_, BN_, WM_, WN_, 1>(g, st))
+    int mtot = 0;
+    for (int c = 0; c < NCLS; ++c) mtot += gs.c[c].M;
+    const int bm = bn == 32 ? 128 : pick_bm(mtot, cdiv(g.N, bn));
+#define YH_CFG(BM_, BN_, WM_, WN_) \
+    (vec ? launch_cfg<BM_, BN_, WM_, WN_, 4, NCLS>(gs, st) : launch_cfg<BM_, BN_, WM_, WN_, 1, NCLS>(gs, st))
     if (bm == 128) {
         if (bn == 32) return YH_CFG(128, 32, 4, 1);
         if (bn == 64) return YH_CFG(128, 64, 2, 2);
         return YH_CFG(128, 128, 2, 2);
     }
-    if (bn == 32) return YH_CFG(128, 32, 4, 1);   // N <= 32 layers always have a huge M
     if (bn == 64) return YH_CFG(64, 64, 2, 2);
     return YH_CFG(64, 128, 2, 2);
 #undef YH_CFG
+}
+
+int launch(const GatherGemm &g, hipStream_t st) {
+    GatherGemmSet gs{};
+    gs.c[0] = g;
+    return launch_set<1>(gs, st);
 }
 
 }  // namespace
@@ -345,7 +387,10 @@ extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int 
     YH_REQUIRE(lddy >= Cout && lddx >= Cin, "conv_bwd_data: ld smaller than channel count");
     const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
     YH_REQUIRE(!(k == 1 && s == 2), "conv_bwd_data: 1x1 stride-2 is not used by this network");
-    // one launch per residue class of the input pixel modulo the stride
+    // one workgroup set per residue class of the input pixel modulo the stride; the (up to four)
+    // classes of a stride-2 pass go out as ONE launch (blockIdx.y = class)
+    GatherGemmSet gs{};
+    int ncls = 0;
     for (int ph = 0; ph < s; ++ph)
         for (int pw = 0; pw < s; ++pw) {
             GatherGemm g{};
@@ -367,8 +412,14 @@ extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int 
             YH_REQUIRE(nt > 0, "conv_bwd_data: residue class without taps");
             g.nTaps = nt; g.Ktot = nt * Cout;
             if (g.M == 0) continue;
-            int rc = launch(g, (hipStream_t)stream);
-            if (rc) return rc;
+            gs.c[ncls++] = g;
         }
-    return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (ncls) {
+        case 0: return 0;
+        case 1: return launch_set<1>(gs, st);
+        case 2: return launch_set<2>(gs, st);
+        case 3: return launch_set<3>(gs, st);
+        default: return launch_set<4>(gs, st);
+    }
 }
