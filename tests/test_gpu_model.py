@@ -190,3 +190,32 @@ def test_cpu_tensor_is_rejected_loudly():
     m = y.ConvBlock(4, 8, 3, 1, 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 4, 8, 8))
+
+
+@pytest.mark.parametrize("nc,S,B", [(80, 320, 2), (80, 1280, 1)])
+def test_other_baseline_configs_match_oracle(nc, S, B):
+    """BASELINE configs 3/4 at reduced batch: nc=80 heads (255 output channels, scalar-dy kernels) and a
+    1280x1280 input, where the loss keeps decoding with img_size=640 (reference quirk Q1)."""
+    y = api()
+    torch.manual_seed(0)
+    m = y.YOLO(num_classes=nc, img_size=S)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(5))
+    targets = y.synthetic_targets(B, nc, S, 8, 77)
+    m = m.cuda()
+    tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
+    before = tr.flat_g.clone()
+    out = tr.step(x.cuda(), [t.cuda() for t in targets]).cpu().numpy()
+    for n in names:
+        P[n].requires_grad_(True)
+    torch.set_num_threads(16)
+    ref = orc.loss_multiscale(orc.forward(P, x, nc, True), targets, orc.anchors_of(P), nc)
+    close(out[:4], [float(v) for v in ref], 1e-4, 1e-6)
+    ref[0].backward()
+    total, coef = orc.clip_coef([P[n].grad for n in names], 10.0)
+    close(float(tr.norm), total, 3e-4, 0)
+    params = dict(m.named_parameters())
+    for n in ("head_p3.2.weight", "head_p5.2.bias", "head_p4.0.conv.weight", "stem.0.weight", "merge_p3.conv3.bn.weight"):
+        r = P[n].grad * coef
+        assert float((params[n].grad.cpu() - r).abs().max()) <= 3e-3 * float(r.abs().max()) + 1e-8, n

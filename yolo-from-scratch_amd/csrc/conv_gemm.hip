@@ -51,15 +51,33 @@ __device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
     return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
 }
 
-template <int BM, int BN, int WM, int WN, int VEC, int NCLS>
+template <int MT> struct Mfma;
+template <> struct Mfma<32> {
+    typedef f32x16 Acc;
+    static constexpr int NR = 16;
+    static __device__ __forceinline__ Acc run(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+};
+template <> struct Mfma<16> {
+    typedef f32x4 Acc;
+    static constexpr int NR = 4;
+    static __device__ __forceinline__ Acc run(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int r, int lh) { return 4 * lh + r; }
+};
+
+template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs) {
     const GatherGemm &g = gs.c[NCLS == 1 ? 0 : blockIdx.y];
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    typedef Mfma<MT> MF;
+    typedef typename MF::Acc Acc;
+    constexpr int LG = 64 / MT;            // lane groups = physical k values one MFMA consumes per lane slot
+    constexpr int KSTEP = 4 * LG;          // k consumed per (ds_read_b128 -> 4 MFMAs) step
+    constexpr int TM = BM / WM / MT, TN = BN / WN / MT;
     constexpr int AROWS = BM / 32;
     constexpr int BQ = BN / 4;
     constexpr int BROWS = 256 / BQ;
-    constexpr int BPASS = BK / BROWS;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BPASS >= 1, "tile shape");
+    constexpr int BPASS = (BK + BROWS - 1) / BROWS;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BK % KSTEP == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                          // [2][BM][LDA]
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
         for (int p = 0; p < BPASS; ++p) {
             int kr = c * BK + t / BQ + p * BROWS;
             int n = n0 + 4 * (t % BQ);
-            if (kr < g.Ktot && n < g.ldw) {
+            if (t / BQ + p * BROWS < BK && kr < g.Ktot && n < g.ldw) {
                 int tap = (int)__umulhi((unsigned)kr, g.cin_magic), ci = kr - tap * g.Cin;
                 rb[p] = *(const f32x4 *)(g.w + ((tapt[18 + tap] * g.Cin + ci) * g.ldw + n));
             } else {
@@ -158,44 +176,46 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) *(f32x4 *)(a + ((t >> 3) + 32 * i) * LDA + 4 * kq) = ra[i];
 #pragma unroll
-        for (int p = 0; p < BPASS; ++p) *(f32x4 *)(b + (t / BQ + p * BROWS) * BN + 4 * (t % BQ)) = rb[p];
+        for (int p = 0; p < BPASS; ++p)
+            if (t / BQ + p * BROWS < BK) *(f32x4 *)(b + (t / BQ + p * BROWS) * BN + 4 * (t % BQ)) = rb[p];
     };
 
-    f32x16 acc[TM][TN];
+    Acc acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < MF::NR; ++r) acc[i][j][r] = 0.f;
 
     const int nchunks = (g.Ktot + BK - 1) / BK;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lr = lane & (MT - 1), lh = lane / MT;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_tiles(c + 1);
-        const float *a = As + buf * BM * LDA + (wm * TM * 32 + lr) * LDA + 4 * lh;
-        const float *b = Bs + buf * BK * BN + (4 * lh) * BN + wn * TN * 32 + lr;
+        const float *a = As + buf * BM * LDA + (wm * TM * MT + lr) * LDA + 4 * lh;
+        const float *b = Bs + buf * BK * BN + (4 * lh) * BN + wn * TN * MT + lr;
+        const int kvalid = g.Ktot - c * BK;      // the last chunk of a short K skips its empty k-steps
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 8) {
+        for (int kk = 0; kk < BK; kk += KSTEP) {
+            if (kk >= kvalid) break;
             f32x4 av[TM];
             float bv[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4 *)(a + i * 32 * LDA + kk);
+            for (int i = 0; i < TM; ++i) av[i] = *(const f32x4 *)(a + i * MT * LDA + kk);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[j][e] = b[(kk + e) * BN + j * 32];
+                for (int e = 0; e < 4; ++e) bv[j][e] = b[(kk + e) * BN + j * MT];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::run(av[i][e], bv[j][e], acc[i][j]);
         }
         if (c + 1 < nchunks) store_tiles(buf ^ 1);
         __syncthreads();
@@ -208,14 +228,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
     float bias_v[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        int n = n0 + wn * TN * 32 + j * 32 + lr;
+        int n = n0 + wn * TN * MT + j * MT + lr;
         bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int r = 0; r < MF::NR; ++r) {
+            int m = m0 + wm * TM * MT + i * MT + MF::row(r, lh);
             if (m >= g.M) continue;
             size_t opix;
             if (g.dense) {
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
             float *orow = g.out + opix * g.ldo;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                int n = n0 + wn * TN * 32 + j * 32 + lr;
+                int n = n0 + wn * TN * MT + j * MT + lr;
                 if (n < g.N) {
                     float v = acc[i][j][r] + bias_v[j];
                     if (g.accumulate) v += orow[n];
@@ -243,10 +263,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
         float *red = smem;   // [WM][BN][2]; the main loop ended with a barrier
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float s = csum[j] + __shfl_xor(csum[j], 32);
-            float q = csq[j] + __shfl_xor(csq[j], 32);
+            float s = csum[j], q = csq[j];
+#pragma unroll
+            for (int o = 32; o >= MT; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }   // lanes sharing a column
             if (lh == 0) {
-                int col = wn * TN * 32 + j * 32 + lr;
+                int col = wn * TN * MT + j * MT + lr;
                 red[(wm * BN + col) * 2 + 0] = s;
                 red[(wm * BN + col) * 2 + 1] = q;
             }
@@ -272,11 +293,11 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
     shift = l - 1;
 }
 
-template <int BM, int BN, int WM, int WN, int VEC, int NCLS>
+template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT>
 int launch_cfg(GatherGemmSet gs, hipStream_t st) {
     constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 27 * sizeof(int);
     static bool attr_set = false;
-    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC, NCLS>;
+    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC, NCLS, MT>;
     if (!attr_set) {
         YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -309,7 +330,7 @@ int pick_bm(int M, int nblk_n) {
 
 int stats_bm(int M, int N) {   // rows per BatchNorm partial-sum block = the BM the forward launch will use
     int bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
-    return bn == 32 ? 128 : pick_bm(M, cdiv(N, bn));
+    return bn <= 32 ? 128 : pick_bm(M, cdiv(N, bn));
 }
 
 template <int NCLS>
@@ -327,12 +348,14 @@ int launch_set(GatherGemmSet &gs, hipStream_t st) {
     }
     const GatherGemm &g = gs.c[0];
     const bool vec = (g.Cin % 4 == 0) && (g.ldi % 4 == 0) && (((uintptr_t)g.in & 15) == 0);
-    const int bn = g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128);
+    const int bn = g.N <= 16 ? 16 : (g.N <= 32 ? 32 : (g.N <= 64 ? 64 : 128));
     int mtot = 0;
     for (int c = 0; c < NCLS; ++c) mtot += gs.c[c].M;
-    const int bm = bn == 32 ? 128 : pick_bm(mtot, cdiv(g.N, bn));
+    const int bm = bn <= 32 ? 128 : pick_bm(mtot, cdiv(g.N, bn));
 #define YH_CFG(BM_, BN_, WM_, WN_) \
-    (vec ? launch_cfg<BM_, BN_, WM_, WN_, 4, NCLS>(gs, st) : launch_cfg<BM_, BN_, WM_, WN_, 1, NCLS>(gs, st))
+    (vec ? launch_cfg<BM_, BN_, WM_, WN_, 4, NCLS, 32>(gs, st) : launch_cfg<BM_, BN_, WM_, WN_, 1, NCLS, 32>(gs, st))
+    // N <= 16: the 16x16x4 MFMA shape (same FLOP rate, no padding of the channel axis to 32)
+    if (bn == 16) return vec ? launch_cfg<128, 16, 4, 1, 4, NCLS, 16>(gs, st) : launch_cfg<128, 16, 4, 1, 1, NCLS, 16>(gs, st);
     if (bm == 128) {
         if (bn == 32) return YH_CFG(128, 32, 4, 1);
         if (bn == 64) return YH_CFG(128, 64, 2, 2);

@@ -246,7 +246,8 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
         int best = 32, best_work = 1 << 30;
         for (int c : cand) {
             int xw = (c - 1) * s + k;
-            if (cdiv(k * xw * (g.CIT / 4), 256) > 7 || (cdiv(k * xw * (g.CIT / 4), 256) > 4 && cdiv(c * (g.COT / 4), 256) > 2)) continue;
+            int xl = cdiv(k * xw * (g.CIT / 4), 256), dl = cdiv(c * (g.COT / 4), 256);
+            if (!((xl <= 4 && dl <= 4) || (xl <= 7 && dl <= 2))) continue;   // staging variants that exist
             int work = cdiv(g.Wo, c) * c;
             if (work < best_work) { best_work = work; best = c; }
         }
