@@ -28,17 +28,35 @@ struct Wgrad {
     int Cin, Cout, k, s, pad;
     int CIT, COT, n_ci_tiles;
     int nseg_row, nseg_total, segs_per_split;
-    int vec_dy, P;
+    int vec_dy, P, MT;
 };
 
 // XL / DL: compile-time upper bounds of the float4 staging loads per thread for the input halo and
 // the dy row, so the loads of the NEXT segment are issued back to back into registers and stay in
 // flight while the MFMAs of the current segment run (register-staged double buffering).
-template <int NT, int XL, int DL>
+template <int MT> struct WMfma;
+template <> struct WMfma<32> {
+    typedef f32x16 Acc;
+    static constexpr int NR = 16;
+    static __device__ __forceinline__ Acc run(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+};
+template <> struct WMfma<16> {
+    typedef f32x4 Acc;
+    static constexpr int NR = 4;
+    static __device__ __forceinline__ Acc run(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int r, int lh) { return 4 * lh + r; }
+};
+
+// MT = MFMA tile edge: 32 (32x32x2, two pixels per instruction) or 16 (16x16x4, four pixels; used when
+// the slab has <= 16 output channels or few (tap, ci) rows, where 32-wide tiles would be mostly padding).
+template <int NT, int XL, int DL, int MT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
+    typedef WMfma<MT> MF;
+    constexpr int LG = 64 / MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lr = lane & (MT - 1), lh = lane / MT;
     const int KK = g.k * g.k;
     const int P = g.P;
     const int XW = (P - 1) * g.s + g.k;
@@ -49,25 +67,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
     const int ci0 = (blockIdx.y % g.n_ci_tiles) * CIT;
     const int co0 = (blockIdx.y / g.n_ci_tiles) * COT;
     const int rows = KK * CIT;
-    const int RT = (rows + 31) / 32, OT = (COT + 31) / 32;
+    const int RT = (rows + MT - 1) / MT, OT = (COT + MT - 1) / MT;
 
     // tiles of this wave: tau = wave + 4u -> (rt, ot)
     int aoff[NT], boff[NT];
     bool avalid[NT], tvalid[NT];
-    f32x16 acc[NT];
+    typename MF::Acc acc[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         int tau = wave + 4 * u;
         tvalid[u] = tau < RT * OT;
         int rt = tvalid[u] ? tau / OT : 0, ot = tvalid[u] ? tau % OT : 0;
-        int row = rt * 32 + lr;
+        int row = rt * MT + lr;
         avalid[u] = row < rows;
         int tap = avalid[u] ? row / CIT : 0, ci = avalid[u] ? row % CIT : 0;
         aoff[u] = ((tap / g.k) * XW + (tap % g.k)) * CIT + ci;
-        int col = ot * 32 + lr;
-        boff[u] = col < COT ? col : 0;   // columns >= COT only exist when COT < 32; their results are never stored
+        int col = ot * MT + lr;
+        boff[u] = col < COT ? col : 0;   // columns >= COT only exist in a ragged last tile; their results are never stored
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        for (int r = 0; r < MF::NR; ++r) acc[u][r] = 0.f;
     }
 
     // fixed staging slots of this thread: slot j handles float4 index t + 256 j
@@ -146,10 +164,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
         store_seg(seg);
         __syncthreads();
         if (seg + 1 < seg_end) load_seg(seg + 1);
-        const int npairs = (pv + 1) >> 1;
+        const int npairs = (pv + LG - 1) / LG;      // MFMA steps: LG pixels each
 #pragma unroll 2
         for (int pp = 0; pp < npairs; ++pp) {
-            const int p = 2 * pp + lh;
+            const int p = LG * pp + lh;
             const int xo = p * g.s * CIT, dofs = p * COT;
             // branch-free: all fragment reads are issued before the MFMAs; tiles past the slab (at most
             // one per wave) multiply zeros / unused columns and are never stored
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
             }
 #pragma unroll
             for (int u = 0; u < NT; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(avalid[u] ? av[u] : 0.f, bv[u], acc[u], 0, 0, 0);
+                acc[u] = MF::run(avalid[u] ? av[u] : 0.f, bv[u], acc[u]);
         }
     }
 
@@ -172,11 +190,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
         if (!tvalid[u]) continue;
         int tau = wave + 4 * u;
         int rt = tau / OT, ot = tau % OT;
-        int col = ot * 32 + lr;
+        int col = ot * MT + lr;
         if (col >= COT || co0 + col >= g.Cout) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int r = 0; r < MF::NR; ++r) {
+            int row = rt * MT + MF::row(r, lh);
             if (row >= rows) continue;
             int tap = row / CIT, ci = ci0 + row % CIT;
             if (ci >= g.Cin) continue;
@@ -238,8 +256,14 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     if (g.CIT % 4) return YH_E_UNSUPPORTED;
     g.n_ci_tiles = cdiv(Cin, g.CIT);
     pl.ntiles = g.n_ci_tiles * cdiv(Cout, g.COT);
-    int RT = cdiv(k * k * g.CIT, 32), OT = cdiv(g.COT, 32);
-    pl.NT = cdiv(RT * OT, 4);
+    {   // MFMA shape: cycles per pixel = tiles32 * 64/2 vs tiles16 * 32/4
+        int t32 = cdiv(k * k * g.CIT, 32) * cdiv(g.COT, 32), t16 = cdiv(k * k * g.CIT, 16) * cdiv(g.COT, 16);
+        static const int force = getenv("YH_WGRAD_MT") ? atoi(getenv("YH_WGRAD_MT")) : 0;   // tuning knob
+        g.MT = (t16 < 4 * t32 && t16 <= 20) ? 16 : 32;
+        if (force == 16 && t16 <= 20) g.MT = 16;
+        if (force == 32) g.MT = 32;
+        pl.NT = cdiv(g.MT == 16 ? t16 : t32, 4);
+    }
     // segment length: the candidate with the least padded work that fits the staging-register budget
     {
         const int cand[4] = {40, 32, 20, 16};
@@ -271,10 +295,10 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     return 0;
 }
 
-template <int NT, int XL, int DL>
+template <int NT, int XL, int DL, int MT>
 int launch_wgrad_cfg(const Plan &pl, hipStream_t st) {
     static size_t attr = 0;
-    auto kern = wgrad_kernel<NT, XL, DL>;
+    auto kern = wgrad_kernel<NT, XL, DL, MT>;
     if (pl.smem > attr) {
         YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
         attr = pl.smem;
@@ -289,9 +313,17 @@ int launch_wgrad(const Plan &pl, hipStream_t st) {
     const Wgrad &g = pl.g;
     const int XW = (g.P - 1) * g.s + g.k;
     const int xl = cdiv(g.k * XW * (g.CIT / 4), 256), dl = cdiv(g.P * (g.COT / 4), 256);
-    if (xl <= 2 && dl <= 2) return launch_wgrad_cfg<NT, 2, 2>(pl, st);
-    if (xl <= 4 && dl <= 4) return launch_wgrad_cfg<NT, 4, 4>(pl, st);
-    if (xl <= 7 && dl <= 2) return launch_wgrad_cfg<NT, 7, 2>(pl, st);
+    if (g.MT == 16) {
+        if constexpr (NT <= 5) {
+            if (xl <= 2 && dl <= 2) return launch_wgrad_cfg<NT, 2, 2, 16>(pl, st);
+            if (xl <= 4 && dl <= 4) return launch_wgrad_cfg<NT, 4, 4, 16>(pl, st);
+            if (xl <= 7 && dl <= 2) return launch_wgrad_cfg<NT, 7, 2, 16>(pl, st);
+        }
+    } else {
+        if (xl <= 2 && dl <= 2) return launch_wgrad_cfg<NT, 2, 2, 32>(pl, st);
+        if (xl <= 4 && dl <= 4) return launch_wgrad_cfg<NT, 4, 4, 32>(pl, st);
+        if (xl <= 7 && dl <= 2) return launch_wgrad_cfg<NT, 7, 2, 32>(pl, st);
+    }
     yh_set_error("conv_bwd_weight: staging shape (%d, %d) unsupported", xl, dl);
     return YH_E_UNSUPPORTED;
 }
