@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
     }
     __syncthreads();
 
-    f32x4 ra[AROWS], rb[BPASS];
-    auto load_tiles = [&](int c) {
+    // two register sets: chunk c+1 and chunk c+2 are both in flight while chunk c is multiplied
+    f32x4 raA[AROWS], rbA[BPASS], raB[AROWS], rbB[BPASS];
+    auto load_tiles = [&](int c, f32x4 (&ra)[AROWS], f32x4 (&rb)[BPASS]) {
         const int k = c * BK + 4 * kq;
         if (VEC == 4) {
             if (k < g.Ktot) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, f32x4 (&ra)[AROWS], f32x4 (&rb)[BPASS]) {
         float *a = As + buf * BM * LDA;
         float *b = Bs + buf * BK * BN;
 #pragma unroll
@@ -190,18 +191,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
 
     const int nchunks = (g.Ktot + BK - 1) / BK;
     const int lr = lane & (MT - 1), lh = lane / MT;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_tiles(c + 1);
+    auto compute = [&](int buf, int kvalid) {
         const float *a = As + buf * BM * LDA + (wm * TM * MT + lr) * LDA + 4 * lh;
         const float *b = Bs + buf * BK * BN + (4 * lh) * BN + wn * TN * MT + lr;
-        const int kvalid = g.Ktot - c * BK;      // the last chunk of a short K skips its empty k-steps
 #pragma unroll
         for (int kk = 0; kk < BK; kk += KSTEP) {
-            if (kk >= kvalid) break;
+            if (kk >= kvalid) break;               // the last chunk of a short K skips its empty k-steps
             f32x4 av[TM];
             float bv[TN][4];
 #pragma unroll
@@ -217,7 +212,22 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = MF::run(av[i][e], bv[j][e], acc[i][j]);
         }
-        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+    };
+    // software pipeline, prefetch distance 2: at step c the loads of chunk c+2 are issued, chunk c is
+    // multiplied from LDS, then chunk c+1 (loaded one step earlier) is written to the other LDS buffer.
+    load_tiles(0, raA, rbA);
+    store_tiles(0, raA, rbA);
+    if (nchunks > 1) load_tiles(1, raB, rbB);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) load_tiles(c + 2, raA, rbA);
+        compute(0, g.Ktot - c * BK);
+        if (c + 1 < nchunks) store_tiles(1, raB, rbB);
+        __syncthreads();
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) load_tiles(c + 3, raB, rbB);
+        compute(1, g.Ktot - (c + 1) * BK);
+        if (c + 2 < nchunks) store_tiles(0, raA, rbA);
         __syncthreads();
     }
 

@@ -165,21 +165,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
         __syncthreads();
         if (seg + 1 < seg_end) load_seg(seg + 1);
         const int npairs = (pv + LG - 1) / LG;      // MFMA steps: LG pixels each
-#pragma unroll 2
-        for (int pp = 0; pp < npairs; ++pp) {
-            const int p = LG * pp + lh;
-            const int xo = p * g.s * CIT, dofs = p * COT;
-            // branch-free: all fragment reads are issued before the MFMAs; tiles past the slab (at most
-            // one per wave) multiply zeros / unused columns and are never stored
-            float av[NT], bv[NT];
+        // two steps per iteration: the fragment reads of step pp+1 are in flight behind the MFMAs of step pp.
+        // Branch-free: tiles past the slab (at most one per wave) multiply zeros / unused columns, never stored.
+        int pp = 0;
+        for (; pp + 1 < npairs; pp += 2) {
+            const int p0 = LG * pp + lh, p1 = p0 + LG;
+            const int xo0 = p0 * g.s * CIT, do0 = p0 * COT, xo1 = p1 * g.s * CIT, do1 = p1 * COT;
+            float a0[NT], b0[NT], a1[NT], b1[NT];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                av[u] = Xs[aoff[u] + xo];
-                bv[u] = Ds[boff[u] + dofs];
-            }
+            for (int u = 0; u < NT; ++u) { a0[u] = Xs[aoff[u] + xo0]; b0[u] = Ds[boff[u] + do0]; }
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
-                acc[u] = MF::run(avalid[u] ? av[u] : 0.f, bv[u], acc[u]);
+            for (int u = 0; u < NT; ++u) { a1[u] = Xs[aoff[u] + xo1]; b1[u] = Ds[boff[u] + do1]; }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = MF::run(avalid[u] ? a0[u] : 0.f, b0[u], acc[u]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = MF::run(avalid[u] ? a1[u] : 0.f, b1[u], acc[u]);
+        }
+        if (pp < npairs) {
+            const int p0 = LG * pp + lh;
+            const int xo0 = p0 * g.s * CIT, do0 = p0 * COT;
+            float a0[NT], b0[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) { a0[u] = Xs[aoff[u] + xo0]; b0[u] = Ds[boff[u] + do0]; }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = MF::run(avalid[u] ? a0[u] : 0.f, b0[u], acc[u]);
         }
     }
 
