@@ -52,6 +52,17 @@ int yh_pack_weights_multi(const void *table, int n_layers, void *stream);
 int yh_conv_fwd(const float *x, int ldx, const float *wf, int ldwf, const float *bias, float *y, int ldy,
                 float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
 int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s);
+/* Inference forward: y = [upsample x2]( silu(conv(x, wf) + bias) + residual ) in ONE kernel; wf / bias come from
+ * yh_pack_fold_multi (eval-mode BatchNorm folded in).  act_silu = 0 gives conv + bias only.
+ * replaces: model.eval() forward of ConvBlock / inline conv+BN+SiLU (train.py:265, 401-418, 244-251) inside
+ * predict (train.py:1140-1141). */
+int yh_conv_fwd_fused(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res, int ldr,
+                      float *y, int ldy, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int act_silu,
+                      int upsample, void *stream);
+/* Fold eval-mode BatchNorm into packed forward weights for n_layers convolutions in one launch.  `table` is a
+ * DEVICE array of 88-byte records { const float *oihw, *bias_in, *gamma, *beta, *running_mean, *running_var;
+ * float *wf, *bias_out; int32 Cout, Cin, k*k, cin_pad, ldwf; float eps } (gamma == NULL: plain pack + bias copy). */
+int yh_pack_fold_multi(const void *table, int n_layers, void *stream);
 /* Backward-data: dx (+)= conv_transpose(dy, w).  replaces: aten::convolution_backward (input
  * gradient) reached from loss.backward() (train.py:913). */
 int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi,
@@ -136,10 +147,12 @@ int yh_ciou(const float *pred, const float *tgt, float *dpred, int64_t N, float 
 /* Candidate extraction of predict() (train.py:1152-1229) for one image: keeps cells with
  * sigmoid(obj) > conf_thr in scale-major, row-major (i,j,a) order.  boxes (cap,4) corners in
  * original-image pixels, scores (cap), classes (cap) int32, count[0] = M (may exceed cap: the
- * caller must check).  ws: >= yh_candidates_ws(grid) ints. */
+ * caller must check).  ws: >= yh_candidates_ws(grid) ints.  letterbox_dev: NULL, or a DEVICE array
+ * {pad_left, pad_top, scale} that overrides the three scalars (so a captured hipGraph can be replayed
+ * with per-image letterbox parameters). */
 int yh_candidates(const float *const pred[3], const float *anchors, const int grid[3], int nc, float img_size,
                   float conf_thr, float pad_left, float pad_top, float scale, float *boxes, float *scores,
-                  int32_t *classes, int32_t *count, int cap, int32_t *ws, void *stream);
+                  int32_t *classes, int32_t *count, int cap, int32_t *ws, const float *letterbox_dev, void *stream);
 int64_t yh_candidates_ws(const int grid[3]);
 /* Class-aware greedy NMS = torchvision.ops.batched_nms as called at train.py:1232-1233: stable
  * descending score order, suppress IoU > thr within a class.  M is read from count[0] on the
@@ -179,7 +192,7 @@ enum {
     YH_OP_NCHW_TO_NHWC = 1, YH_OP_NHWC_TO_NCHW, YH_OP_PACK_WEIGHTS, YH_OP_CONV_FWD, YH_OP_CONV_BWD_DATA,
     YH_OP_CONV_BWD_WEIGHT, YH_OP_COLSUM, YH_OP_BN_FINALIZE, YH_OP_BN_EVAL_COEF, YH_OP_BN_SILU_FWD,
     YH_OP_BN_SILU_BWD_REDUCE, YH_OP_BN_SILU_BWD_APPLY, YH_OP_MAXPOOL5_FWD, YH_OP_MAXPOOL5_BWD, YH_OP_MEMSET,
-    YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI
+    YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI, YH_OP_PACK_FOLD_MULTI, YH_OP_CONV_FWD_FUSED
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Backward-weight and column-sum ops are forked onto an

@@ -219,3 +219,42 @@ def test_other_baseline_configs_match_oracle(nc, S, B):
     for n in ("head_p3.2.weight", "head_p5.2.bias", "head_p4.0.conv.weight", "stem.0.weight", "merge_p3.conv3.bn.weight"):
         r = P[n].grad * coef
         assert float((params[n].grad.cpu() - r).abs().max()) <= 3e-3 * float(r.abs().max()) + 1e-8, n
+
+
+def test_inference_session_graph_replay_matches_eager_and_oracle():
+    """BASELINE config 5 plumbing: BN-folded fused forward + candidates + NMS under a captured hipGraph give the
+    same detections as the eager launch sequence and as the CPU oracle pipeline."""
+    y = api()
+    torch.manual_seed(11)
+    m = y.YOLO(num_classes=3, img_size=320)
+    m.initialize_detection_biases(prior=0.3)
+    with torch.no_grad():
+        for hd in (m.head_p3, m.head_p4, m.head_p5):
+            hd[-1].weight.mul_(30.0)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.8, 1.2); mod.bias.uniform_(-0.1, 0.1)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    imgs = [torch.rand(1, 3, 320, 320, generator=torch.Generator().manual_seed(s)) for s in (1, 2)]
+    eager = y.InferenceSession(m, conf_threshold=0.3, iou_threshold=0.4, use_graph=False)
+    graph = y.InferenceSession(m, conf_threshold=0.3, iou_threshold=0.4, use_graph=True)
+    for k, img in enumerate(imgs):
+        lb = (3.0 * k, 1.0 * k, 1.0 - 0.25 * k)
+        de = eager.run(img, *lb)
+        dg = graph.run(img, *lb)
+        assert len(de) > 5 and de == dg
+        with torch.no_grad():
+            preds = orc.forward(P, img, 3, training=False)
+        b, s, c = orc.candidates(preds, orc.anchors_of(P), 320, 3, 0.3, lb[0], lb[1], lb[2])
+        M = int(graph.det.count.item())
+        assert abs(M - len(s)) <= max(2, len(s) // 100)              # cells within an ulp of the threshold may flip
+        keep = orc.nms_batched(graph.det.boxes[:M].cpu().numpy(), graph.det.scores[:M].cpu().numpy(),
+                               graph.det.classes[:M].cpu().numpy(), 0.4)
+        got = graph.det.keep[: int(graph.det.nkeep.item())].cpu().numpy()
+        np.testing.assert_array_equal(got, keep)
+        with torch.no_grad():
+            hip_preds = m(img.cuda())
+        for a, r in zip(hip_preds, preds):
+            assert float((a.cpu() - r).abs().max()) < 2e-3 * max(1.0, float(r.abs().max()))

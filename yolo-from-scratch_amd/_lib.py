@@ -26,7 +26,8 @@ class YhOp(C.Structure):
 # op kinds, same order as the enum in yolohip.h
 (OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_PACK_WEIGHTS, OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT,
  OP_COLSUM, OP_BN_FINALIZE, OP_BN_EVAL_COEF, OP_BN_SILU_FWD, OP_BN_SILU_BWD_REDUCE, OP_BN_SILU_BWD_APPLY,
- OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI) = range(1, 18)
+ OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI, OP_PACK_FOLD_MULTI,
+ OP_CONV_FWD_FUSED) = range(1, 20)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -41,6 +42,8 @@ _SIGS = {
     "yh_pack_weights": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_weights_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_pack_fold_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
@@ -62,7 +65,7 @@ _SIGS = {
     "yh_decode_bwd": (i32, [c_fp, c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
     "yh_ciou": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, c_fp, c_fp, c_fp]),
     "yh_candidates": (i32, [_PP, C.POINTER(f32), _IP, i32, f32, f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, i32, c_fp,
-                            c_fp]),
+                            c_fp, c_fp]),
     "yh_candidates_ws": (i64, [_IP]),
     "yh_nms": (i32, [c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp, c_fp, c_fp, c_fp]),
     "yh_nms_ws": (i64, [i32]),

@@ -71,6 +71,12 @@ static int run_one(const yh_op &o, void *st) {
             return yh_add_int64((int64_t *)p[0], o.l[0], st);
         case YH_OP_PACK_WEIGHTS_MULTI:
             return yh_pack_weights_multi(p[0], i[0], st);
+        case YH_OP_PACK_FOLD_MULTI:
+            return yh_pack_fold_multi(p[0], i[0], st);
+        case YH_OP_CONV_FWD_FUSED:
+            return yh_conv_fwd_fused((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
+                                     (const float *)p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9],
+                                     i[10], i[11], i[12], st);
         default:
             yh_set_error("yh_run: unknown op kind %d", o.kind);
             return YH_E_BADARG;

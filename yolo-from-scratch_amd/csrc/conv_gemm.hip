@@ -33,6 +33,8 @@ struct GatherGemm {
     int sy, sx;
     int nTaps, Ktot;
     int accumulate, dense;
+    const float *res;     // inference epilogue: + residual (after the activation), ld = ldr
+    int ldr, act, up2;    // act: 1 = SiLU on (acc + bias); up2: replicate each output pixel 2x2 (nearest upsample)
     int nblk_n;
     unsigned cin_magic;   // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, magic) for k < 2^16
     unsigned xo_magic, yo_magic;   // exact division of a pixel index < 2^31 by Xo / Yo (see fast_div)
@@ -255,14 +257,27 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
                 int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
                 opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
             }
-            float *orow = g.out + opix * g.ldo;
+            size_t opix_up = 0;
+            if (g.up2) {   // output tensor is (B, 2*Ho_f, 2*Wo_f): top-left pixel of the 2x2 replica
+                int q = fast_div(m, g.xo_magic, g.xo_shift), x = m - q * g.Xo;
+                int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
+                opix_up = ((size_t)b * (2 * g.Ho_f) + 2 * y) * (2 * g.Wo_f) + 2 * x;
+            }
+            float *orow = g.out + (g.up2 ? opix_up : opix) * g.ldo;
+            const float *rrow = g.res ? g.res + opix * g.ldr : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int n = n0 + wn * TN * MT + j * MT + lr;
                 if (n < g.N) {
                     float v = acc[i][j][r] + bias_v[j];
+                    if (g.act) v = v * yh_sigmoid(v);
+                    if (rrow) v += rrow[n];
                     if (g.accumulate) v += orow[n];
                     orow[n] = v;
+                    if (g.up2) {
+                        const size_t rs = (size_t)(2 * g.Wo_f) * g.ldo;
+                        orow[g.ldo + n] = v; orow[rs + n] = v; orow[rs + g.ldo + n] = v;
+                    }
                     csum[j] += v;
                     csq[j] += v * v;
                 }
@@ -405,6 +420,29 @@ extern "C" int yh_conv_fwd(const float *x, int ldx, const float *wf, int ldwf, c
     g.B = B; g.Yo = g.Ho_f; g.Xo = g.Wo_f; g.M = B * g.Yo * g.Xo;
     g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
     g.nTaps = k * k; g.Ktot = g.nTaps * Cin; g.accumulate = 0; g.dense = 1;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            int t = kh * k + kw;
+            g.tap_dy[t] = kh - p; g.tap_dx[t] = kw - p; g.tap_w[t] = t;
+        }
+    return launch(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_fwd_fused(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res,
+                                 int ldr, float *y, int ldy, int B, int Hi, int Wi, int Cin, int Cout, int k, int s,
+                                 int act_silu, int upsample, void *stream) {
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_fwd_fused: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_fwd_fused: bad argument");
+    YH_REQUIRE(ldx >= Cin && ldy >= Cout && (!res || ldr >= Cout), "conv_fwd_fused: ld smaller than channel count");
+    GatherGemm g{};
+    const int p = k / 2;
+    g.in = x; g.w = wf; g.bias = bias; g.out = y; g.stats = nullptr;
+    g.Hi = Hi; g.Wi = Wi; g.ldi = ldx; g.Cin = Cin; g.ldw = ldwf;
+    g.Ho_f = (Hi + 2 * p - k) / s + 1; g.Wo_f = (Wi + 2 * p - k) / s + 1; g.ldo = ldy; g.N = Cout;
+    g.B = B; g.Yo = g.Ho_f; g.Xo = g.Wo_f; g.M = B * g.Yo * g.Xo;
+    g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
+    g.nTaps = k * k; g.Ktot = g.nTaps * Cin; g.accumulate = 0; g.dense = 1;
+    g.res = res; g.ldr = ldr; g.act = act_silu ? 1 : 0; g.up2 = upsample ? 1 : 0;
     for (int kh = 0; kh < k; ++kh)
         for (int kw = 0; kw < k; ++kw) {
             int t = kh * k + kw;

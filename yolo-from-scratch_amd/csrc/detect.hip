@@ -26,6 +26,7 @@ struct CandArgs {
     int cell_begin[4];
     int nc, cap;
     float img, thr, pad_left, pad_top, scale;
+    const float *lb;      // optional device {pad_left, pad_top, scale}: per-image values under hipGraph replay
     float *boxes, *scores;
     int32_t *classes, *count, *blk;   // blk: [nblk] counts then [nblk] offsets
     int nblk;
@@ -98,8 +99,9 @@ __global__ void cand_write_kernel(const CandArgs a) {
     // pixels -> corners -> un-letterbox (train.py:1192-1213), same operation order
     float xc = bx * a.img, yc = by * a.img, wp = bw * a.img, hp = bh * a.img;
     float x1 = xc - wp / 2, y1 = yc - hp / 2, x2 = xc + wp / 2, y2 = yc + hp / 2;
-    x1 = (x1 - a.pad_left) / a.scale; y1 = (y1 - a.pad_top) / a.scale;
-    x2 = (x2 - a.pad_left) / a.scale; y2 = (y2 - a.pad_top) / a.scale;
+    const float pl = a.lb ? a.lb[0] : a.pad_left, pt = a.lb ? a.lb[1] : a.pad_top, sc = a.lb ? a.lb[2] : a.scale;
+    x1 = (x1 - pl) / sc; y1 = (y1 - pt) / sc;
+    x2 = (x2 - pl) / sc; y2 = (y2 - pt) / sc;
     a.boxes[4 * pos + 0] = x1; a.boxes[4 * pos + 1] = y1; a.boxes[4 * pos + 2] = x2; a.boxes[4 * pos + 3] = y2;
     a.scores[pos] = obj * cp;
     a.classes[pos] = cid;
@@ -262,7 +264,8 @@ extern "C" int64_t yh_candidates_ws(const int grid[3]) {
 
 extern "C" int yh_candidates(const float *const pred[3], const float *anchors, const int grid[3], int nc, float img_size,
                              float conf_thr, float pad_left, float pad_top, float scale, float *boxes, float *scores,
-                             int32_t *classes, int32_t *count, int cap, int32_t *ws, void *stream) {
+                             int32_t *classes, int32_t *count, int cap, int32_t *ws, const float *letterbox_dev,
+                             void *stream) {
     YH_REQUIRE(pred && anchors && grid && boxes && scores && classes && count && ws && cap > 0 && nc >= 1,
                "candidates: bad argument");
     YH_REQUIRE(((uintptr_t)boxes & 15) == 0, "candidates: boxes must be 16-byte aligned");
@@ -277,7 +280,7 @@ extern "C" int yh_candidates(const float *const pred[3], const float *anchors, c
     a.cell_begin[3] = cells;
     for (int k = 0; k < 18; ++k) a.anchors[k] = anchors[k];
     a.nc = nc; a.cap = cap; a.img = img_size; a.thr = conf_thr;
-    a.pad_left = pad_left; a.pad_top = pad_top; a.scale = scale;
+    a.pad_left = pad_left; a.pad_top = pad_top; a.scale = scale; a.lb = letterbox_dev;
     a.boxes = boxes; a.scores = scores; a.classes = classes; a.count = count; a.blk = ws;
     a.nblk = cdiv(cells, 256);
     hipStream_t st = (hipStream_t)stream;

@@ -73,6 +73,38 @@ __global__ void pack_weights_multi_kernel(const PackDesc *__restrict__ tab) {
     }
 }
 
+// Inference: fold eval-mode BatchNorm into the packed forward weights and a per-channel bias,
+//   w'[.., n] = w[n, ..] * gamma[n] / sqrt(rv[n] + eps),   b'[n] = (b[n] - rm[n]) * that + beta[n].
+struct FoldDesc {
+    const float *w, *bias_in, *gamma, *beta, *rmean, *rvar;
+    float *wf, *bias_out;
+    int Cout, Cin, kk, cin_pad, ldwf;
+    float eps;
+};
+__global__ void pack_fold_multi_kernel(const FoldDesc *__restrict__ tab) {
+    const FoldDesc d = tab[blockIdx.y];
+    const int nf = d.kk * d.cin_pad * d.ldwf;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
+        int n = i % d.ldwf, q = i / d.ldwf;
+        int ci = q % d.cin_pad, t = q / d.cin_pad;
+        float v = 0.f;
+        if (n < d.Cout && ci < d.Cin) {
+            float sc = d.gamma ? d.gamma[n] * (1.0f / sqrtf(d.rvar[n] + d.eps)) : 1.f;
+            v = d.w[((size_t)n * d.Cin + ci) * d.kk + t] * sc;
+        }
+        d.wf[i] = v;
+    }
+    if (blockIdx.x == 0 && d.bias_out)
+        for (int n = threadIdx.x; n < d.Cout; n += blockDim.x) {
+            float b = d.bias_in ? d.bias_in[n] : 0.f;
+            if (d.gamma) {
+                float sc = d.gamma[n] * (1.0f / sqrtf(d.rvar[n] + d.eps));
+                b = (b - d.rmean[n]) * sc + d.beta[n];
+            }
+            d.bias_out[n] = b;
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column sums: stage 1 -> partial[blk][C], stage 2 -> out[C]
 // vector path (C % 4 == 0, 16-byte addressable rows): float4 columns x row groups, like the BN reductions
@@ -430,6 +462,15 @@ extern "C" int yh_pack_weights_multi(const void *table, int n_layers, void *stre
     hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(32, n_layers), dim3(256), 0, (hipStream_t)stream,
                        (const PackDesc *)table);
     YH_CHECK_LAUNCH("pack_weights_multi");
+    return 0;
+}
+
+extern "C" int yh_pack_fold_multi(const void *table, int n_layers, void *stream) {
+    YH_REQUIRE(table && n_layers > 0, "pack_fold_multi: bad argument");
+    static_assert(sizeof(FoldDesc) == 88, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(pack_fold_multi_kernel, dim3(32, n_layers), dim3(256), 0, (hipStream_t)stream,
+                       (const FoldDesc *)table);
+    YH_CHECK_LAUNCH("pack_fold_multi");
     return 0;
 }
 

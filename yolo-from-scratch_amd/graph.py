@@ -177,42 +177,54 @@ class Plan:
         fwd: List[L.YhOp] = []
         keep: List[torch.Tensor] = []          # tensors referenced only through raw pointers
         packs: List[tuple] = []                # one descriptor per conv for the single pack launch
+        folds: List[tuple] = []                # inference: BN folded into the packed weights
         for r in self.recs:
             if isinstance(r, ConvRec):
                 kk = r.k * r.k
                 r.ldwf, r.ldwb = _rup4(r.cout), _rup4(r.cin)
                 r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
+                if not self.training:
+                    # eval: one fused kernel per conv -- conv + folded-BN bias + SiLU (+residual) (+x2 upsample)
+                    fbias = torch.empty(r.cout, **f32)
+                    keep.append(fbias)
+                    bn = r.bn
+                    folds.append((r.weight.data_ptr(), r.bias.data_ptr() if r.bias is not None else 0,
+                                  bn.weight.data_ptr() if bn is not None else 0, bn.bias.data_ptr() if bn is not None else 0,
+                                  bn.running_mean.data_ptr() if bn is not None else 0,
+                                  bn.running_var.data_ptr() if bn is not None else 0, r.wf.data_ptr(), fbias.data_ptr(),
+                                  r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, float(bn.eps) if bn is not None else 0.0))
+                    fwd.append(_op(L.OP_CONV_FWD_FUSED,
+                                   p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()],
+                                   i=[r.x.ld, r.ldwf, r.residual.ld if r.residual else 0, r.out.ld, r.x.B, r.x.H, r.x.W,
+                                      r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)]))
+                    continue
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
                 r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
                 packs.append((r.weight.data_ptr(), r.wf.data_ptr(), r.wb.data_ptr() if r.wb is not None else 0,
                               r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
+                r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32) if r.bn is not None else None
                 if r.bn is not None:
-                    r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32)
                     r.coef = torch.empty(4 * r.cout, **f32)
                     ytarget, ldy = r.y, r.cout
                 else:
                     ytarget, ldy = None, r.out.ld
                 nblk = lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                 M = r.x.B * r.Ho * r.Wo
-                if r.bn is not None and self.training:
+                if r.bn is not None:
                     nb_bwd = lib.yh_bn_bwd_blocks(M, r.cout)
                     r.part = torch.empty(max(nblk, nb_bwd) * 2 * r.cout, **f32)
-                if r.bn is not None and not self.training:
-                    fwd.append(_op(L.OP_BN_EVAL_COEF, p=[r.bn.weight, r.bn.bias, r.bn.running_mean, r.bn.running_var, r.coef],
-                                   i=[r.cout], f=[r.bn.eps]))
                 fwd.append(_op(L.OP_CONV_FWD,
                                p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
-                                  r.part if (r.bn is not None and self.training) else None],
+                                  r.part if r.bn is not None else None],
                                i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s]))
                 if r.bn is not None:
-                    if self.training:
-                        track = r.bn.track_running_stats and r.bn.running_mean is not None
-                        mom = r.bn.momentum if r.bn.momentum is not None else 0.1
-                        fwd.append(_op(L.OP_BN_FINALIZE,
-                                       p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
-                                          r.bn.running_var if track else None, r.coef,
-                                          r.bn.num_batches_tracked if track else None],
-                                       i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M]))
+                    track = r.bn.track_running_stats and r.bn.running_mean is not None
+                    mom = r.bn.momentum if r.bn.momentum is not None else 0.1
+                    fwd.append(_op(L.OP_BN_FINALIZE,
+                                   p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
+                                      r.bn.running_var if track else None, r.coef,
+                                      r.bn.num_batches_tracked if track else None],
+                                   i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M]))
                     fwd.append(_op(L.OP_BN_SILU_FWD,
                                    p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
                                    i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
@@ -221,6 +233,11 @@ class Plan:
                 r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
                 fwd.append(_op(L.OP_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
                                i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C]))
+        if folds:
+            import struct
+            blob = b"".join(struct.pack("<QQQQQQQQiiiiif", *d) for d in folds)
+            self.fold_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            fwd.insert(0, _op(L.OP_PACK_FOLD_MULTI, p=[self.fold_table], i=[len(folds)]))
         if packs:   # every conv's OIHW -> packed copies in ONE launch at the head of the forward list
             import struct
             blob = b"".join(struct.pack("<QQQiiiiiiii", *d, 0, 0) for d in packs)

@@ -36,7 +36,7 @@ class Detector:
         self.ws_n = torch.empty(int(L.lib().yh_nms_ws(self.cap)) + 256, device=device, dtype=torch.uint8)
 
     def candidates(self, preds: Sequence[torch.Tensor], anchors_list, img_size, conf_threshold, pad_left=0.0,
-                   pad_top=0.0, scale=1.0):
+                   pad_top=0.0, scale=1.0, letterbox_dev: torch.Tensor = None):
         for p, g in zip(preds, self.grids):
             if tuple(p.shape) != (1, g, g, 3, 5 + self.nc) or not p.is_contiguous():
                 raise ValueError(f"expected contiguous (1,{g},{g},3,{5 + self.nc}) predictions, got {tuple(p.shape)}")
@@ -44,6 +44,7 @@ class Detector:
                                       float(img_size), float(conf_threshold), float(pad_left), float(pad_top),
                                       float(scale), self.boxes.data_ptr(), self.scores.data_ptr(),
                                       self.classes.data_ptr(), self.count.data_ptr(), self.cap, self.ws_c.data_ptr(),
+                                      letterbox_dev.data_ptr() if letterbox_dev is not None else None,
                                       _stream(self.device)), "candidates")
 
     def nms(self, iou_threshold: float):
@@ -102,3 +103,53 @@ def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_th
     det.candidates(preds, model.anchors, img_size, conf_threshold, pad_left, pad_top, scale)
     det.nms(iou_threshold)
     return det.fetch()
+
+
+class InferenceSession:
+    """bs=1 end-to-end inference (BASELINE config 5): NCHW->NHWC, BN-folded fused convs, candidate
+    extraction and global NMS, captured ONCE into a hipGraph (via torch.cuda.CUDAGraph on the launch
+    stream) and replayed per image.  Everything the graph touches has a fixed address: the input image,
+    the letterbox parameters {pad_left, pad_top, scale} and all outputs live in static device buffers."""
+
+    def __init__(self, model, conf_threshold=0.5, iou_threshold=0.4, use_graph=True):
+        self.model = model.eval()
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("InferenceSession: the HIP path needs the model on the GPU; no CPU fallback in this package")
+        self.device, self.S, self.nc = p0.device, model.img_size, model.num_classes
+        self.conf, self.iou = float(conf_threshold), float(iou_threshold)
+        self.x = torch.zeros(1, 3, self.S, self.S, device=self.device)
+        self.lb = torch.tensor([0.0, 0.0, 1.0], device=self.device)
+        with torch.no_grad():
+            self.plan = model._plan_for(self.x)
+        self.heads = [v for v, _ in self.plan.outputs]
+        self.det = Detector([v.H for v in self.heads], self.nc, self.device)
+        self.graph = None
+        if use_graph:
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._enqueue()            # warm-up: kernel attributes, lazy module state
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._enqueue()
+
+    def _enqueue(self):
+        self.model._load_input(self.plan, self.x)
+        self.plan.run_forward(_stream(self.device))
+        preds = [v.buf.data.view(1, v.H, v.W, 3, v.C // 3) for v in self.heads]
+        self.det.candidates(preds, self.model.anchors, self.S, self.conf, letterbox_dev=self.lb)
+        self.det.nms(self.iou)
+
+    def run(self, img: torch.Tensor, pad_left=0.0, pad_top=0.0, scale=1.0, fetch=True):
+        """img: (1,3,S,S) or (3,S,S) float tensor (host or device).  Returns the detections list."""
+        self.x.copy_(img.reshape(self.x.shape), non_blocking=True)
+        self.lb.copy_(torch.tensor([pad_left, pad_top, scale], dtype=torch.float32), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+        return self.det.fetch() if fetch else None
