@@ -159,8 +159,13 @@ def main():
         conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
         flops = plan_conv_flops(plan) * BATCH
         ach = flops / (conv_ms * 1e-3) / 1e12
+        traffic = None          # HBM bytes of the same 62 launches, from the committed rocprofv3 PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                              "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                              "traffic_note": "bytes per step over the same 62 launches (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.json); algorithmic 8.41e9",
                               "kernel": "gather_gemm_kernel (forward convolutions)", "launches_per_step": n_launch,
                               "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
         result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items())}
