@@ -69,24 +69,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
     const int rows = KK * CIT;
     const int RT = (rows + MT - 1) / MT, OT = (COT + MT - 1) / MT;
 
-    // tiles of this wave: tau = wave + 4u -> (rt, ot)
-    int aoff[NT], boff[NT];
-    bool avalid[NT], tvalid[NT];
+    // tile ownership: a wave owns ONE column tile (so a single dy fragment per step feeds all its MFMAs)
+    // and every WR-th row tile: ot = wave % OT, rt = wave / OT + WR * u, WR = 4 / OT (OT is 1, 2 or 4).
+    // Rows / columns past the slab read in-bounds garbage whose products are never stored: no masks.
+    const int WR = 4 / OT;
+    const int ot = wave % OT, wr = wave / OT;
+    int aoff[NT];
     typename MF::Acc acc[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        int tau = wave + 4 * u;
-        tvalid[u] = tau < RT * OT;
-        int rt = tvalid[u] ? tau / OT : 0, ot = tvalid[u] ? tau % OT : 0;
-        int row = rt * MT + lr;
-        avalid[u] = row < rows;
-        int tap = avalid[u] ? row / CIT : 0, ci = avalid[u] ? row % CIT : 0;
+        int row = (wr + WR * u) * MT + lr;
+        if (row >= rows) row = lr % rows;
+        int tap = row / CIT, ci = row % CIT;
         aoff[u] = ((tap / g.k) * XW + (tap % g.k)) * CIT + ci;
-        int col = ot * MT + lr;
-        boff[u] = col < COT ? col : 0;   // columns >= COT only exist in a ragged last tile; their results are never stored
 #pragma unroll
         for (int r = 0; r < MF::NR; ++r) acc[u][r] = 0.f;
     }
+    const int bcol = ot * MT + lr;
+    const int boff = bcol < COT ? bcol : 0;
 
     // fixed staging slots of this thread: slot j handles float4 index t + 256 j
     const int citq = CIT >> 2, cotq = COT >> 2;
@@ -170,44 +170,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
         int pp = 0;
         for (; pp + 1 < npairs; pp += 2) {
             const int p0 = LG * pp + lh, p1 = p0 + LG;
-            const int xo0 = p0 * g.s * CIT, do0 = p0 * COT, xo1 = p1 * g.s * CIT, do1 = p1 * COT;
-            float a0[NT], b0[NT], a1[NT], b1[NT];
+            const float *x0 = Xs + p0 * g.s * CIT, *x1 = Xs + p1 * g.s * CIT;
+            const float b0 = Ds[boff + p0 * COT], b1 = Ds[boff + p1 * COT];
+            float a0[NT], a1[NT];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) { a0[u] = Xs[aoff[u] + xo0]; b0[u] = Ds[boff[u] + do0]; }
+            for (int u = 0; u < NT; ++u) { a0[u] = x0[aoff[u]]; a1[u] = x1[aoff[u]]; }
 #pragma unroll
-            for (int u = 0; u < NT; ++u) { a1[u] = Xs[aoff[u] + xo1]; b1[u] = Ds[boff[u] + do1]; }
+            for (int u = 0; u < NT; ++u) acc[u] = MF::run(a0[u], b0, acc[u]);
 #pragma unroll
-            for (int u = 0; u < NT; ++u) acc[u] = MF::run(avalid[u] ? a0[u] : 0.f, b0[u], acc[u]);
-#pragma unroll
-            for (int u = 0; u < NT; ++u) acc[u] = MF::run(avalid[u] ? a1[u] : 0.f, b1[u], acc[u]);
+            for (int u = 0; u < NT; ++u) acc[u] = MF::run(a1[u], b1, acc[u]);
         }
         if (pp < npairs) {
             const int p0 = LG * pp + lh;
-            const int xo0 = p0 * g.s * CIT, do0 = p0 * COT;
-            float a0[NT], b0[NT];
+            const float *x0 = Xs + p0 * g.s * CIT;
+            const float b0 = Ds[boff + p0 * COT];
+            float a0[NT];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) { a0[u] = Xs[aoff[u] + xo0]; b0[u] = Ds[boff[u] + do0]; }
+            for (int u = 0; u < NT; ++u) a0[u] = x0[aoff[u]];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) acc[u] = MF::run(avalid[u] ? a0[u] : 0.f, b0[u], acc[u]);
+            for (int u = 0; u < NT; ++u) acc[u] = MF::run(a0[u], b0, acc[u]);
         }
     }
 
     // write this split's partial slab: ws[split][tap][ci][co]
     float *wsp = g.ws + (size_t)blockIdx.x * KK * g.Cin * g.Cout;
+    if (bcol < COT && co0 + bcol < g.Cout) {
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        if (!tvalid[u]) continue;
-        int tau = wave + 4 * u;
-        int rt = tau / OT, ot = tau % OT;
-        int col = ot * MT + lr;
-        if (col >= COT || co0 + col >= g.Cout) continue;
+        for (int u = 0; u < NT; ++u) {
+            const int rt = wr + WR * u;
 #pragma unroll
-        for (int r = 0; r < MF::NR; ++r) {
-            int row = rt * MT + MF::row(r, lh);
-            if (row >= rows) continue;
-            int tap = row / CIT, ci = ci0 + row % CIT;
-            if (ci >= g.Cin) continue;
-            wsp[((size_t)tap * g.Cin + ci) * g.Cout + co0 + col] = acc[u][r];
+            for (int r = 0; r < MF::NR; ++r) {
+                int row = rt * MT + MF::row(r, lh);
+                if (row >= rows) continue;
+                int tap = row / CIT, ci = ci0 + row % CIT;
+                if (ci >= g.Cin) continue;
+                wsp[((size_t)tap * g.Cin + ci) * g.Cout + co0 + bcol] = acc[u][r];
+            }
         }
     }
 }
@@ -271,7 +269,9 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
         g.MT = (t16 < 4 * t32 && t16 <= 20) ? 16 : 32;
         if (force == 16 && t16 <= 20) g.MT = 16;
         if (force == 32) g.MT = 32;
-        pl.NT = cdiv(g.MT == 16 ? t16 : t32, 4);
+        int RT = cdiv(k * k * g.CIT, g.MT), OT = cdiv(g.COT, g.MT);
+        if (OT != 1 && OT != 2 && OT != 4) return YH_E_UNSUPPORTED;
+        pl.NT = cdiv(RT, 4 / OT);
     }
     // segment length: the candidate with the least padded work that fits the staging-register budget
     {
