@@ -183,7 +183,8 @@ int yh_add_int64(int64_t *p, int64_t v, void *stream);
  * arguments in declaration order (pointers in p[], ints in i[], floats in f[]). */
 typedef struct yh_op {
     int32_t kind;
-    int32_t i[20];
+    int32_t lane;      /* 0 = the caller's stream; 1 = the library's side stream (between YH_OP_FORK / YH_OP_JOIN) */
+    int32_t i[19];
     float f[4];
     void *p[12];
     int64_t l[2];
@@ -192,13 +193,17 @@ enum {
     YH_OP_NCHW_TO_NHWC = 1, YH_OP_NHWC_TO_NCHW, YH_OP_PACK_WEIGHTS, YH_OP_CONV_FWD, YH_OP_CONV_BWD_DATA,
     YH_OP_CONV_BWD_WEIGHT, YH_OP_COLSUM, YH_OP_BN_FINALIZE, YH_OP_BN_EVAL_COEF, YH_OP_BN_SILU_FWD,
     YH_OP_BN_SILU_BWD_REDUCE, YH_OP_BN_SILU_BWD_APPLY, YH_OP_MAXPOOL5_FWD, YH_OP_MAXPOOL5_BWD, YH_OP_MEMSET,
-    YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI, YH_OP_PACK_FOLD_MULTI, YH_OP_CONV_FWD_FUSED
+    YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI, YH_OP_PACK_FOLD_MULTI, YH_OP_CONV_FWD_FUSED,
+    YH_OP_FORK,   /* side lane waits for everything issued on the caller's stream so far */
+    YH_OP_JOIN    /* caller's stream waits for everything issued on the side lane so far */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
- * (failing index in *failed when non-NULL).  Backward-weight and column-sum ops are forked onto an
- * internal side stream (they only feed the optimiser) and joined back into `stream` before the call
- * returns, so stream order is preserved for the caller; yh_set_overlap(0) (or YH_OVERLAP=0) disables
- * the fork. */
+ * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side
+ * stream, ordered against the caller's stream only at YH_OP_FORK / YH_OP_JOIN records (independent
+ * sub-graphs, e.g. detection heads next to the neck).  Backward-weight and column-sum ops are forked
+ * automatically (they only feed the optimiser).  Everything is joined back into `stream` before the call
+ * returns, so stream order is preserved for the caller; yh_set_overlap(0) (or YH_OVERLAP=0) runs the
+ * whole list in order on `stream`. */
 int yh_run(const yh_op *ops, int n, void *stream, int *failed);
 int yh_set_overlap(int enable);
 

@@ -19,7 +19,7 @@ i32, i64, f32 = C.c_int, C.c_int64, C.c_float
 
 class YhOp(C.Structure):
     """Mirror of `struct yh_op` (include/yolohip.h)."""
-    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 20), ("f", C.c_float * 4),
+    _fields_ = [("kind", C.c_int32), ("lane", C.c_int32), ("i", C.c_int32 * 19), ("f", C.c_float * 4),
                 ("p", C.c_void_p * 12), ("l", C.c_int64 * 2)]
 
 
@@ -27,7 +27,7 @@ class YhOp(C.Structure):
 (OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_PACK_WEIGHTS, OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT,
  OP_COLSUM, OP_BN_FINALIZE, OP_BN_EVAL_COEF, OP_BN_SILU_FWD, OP_BN_SILU_BWD_REDUCE, OP_BN_SILU_BWD_APPLY,
  OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI, OP_PACK_FOLD_MULTI,
- OP_CONV_FWD_FUSED) = range(1, 20)
+ OP_CONV_FWD_FUSED, OP_FORK, OP_JOIN) = range(1, 22)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3

@@ -120,11 +120,28 @@ extern "C" int yh_run(const yh_op *ops, int n, void *stream, int *failed) {
     hipStream_t mainst = (hipStream_t)stream;
     bool forked = false;
     for (int k = 0; k < n; ++k) {
-        const bool side = (ops[k].kind == YH_OP_CONV_BWD_WEIGHT || ops[k].kind == YH_OP_COLSUM) && side_ready();
+        const int kind = ops[k].kind;
+        if (kind == YH_OP_FORK || kind == YH_OP_JOIN) {      // explicit lane synchronisation points
+            if (!side_ready()) continue;                       // overlap disabled: everything runs in list order on `stream`
+            if (kind == YH_OP_FORK) {                          // side lane may proceed past everything enqueued on main so far
+                YH_HIP(hipEventRecord(g_fork, mainst));
+                YH_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+                forked = true;
+            } else if (forked) {                               // main waits for everything enqueued on the side lane so far
+                YH_HIP(hipEventRecord(g_join, g_side));
+                YH_HIP(hipStreamWaitEvent(mainst, g_join, 0));
+                forked = false;
+            }
+            continue;
+        }
+        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_COLSUM);
+        const bool side = (auto_side || ops[k].lane == 1) && side_ready();
         int rc;
         if (side) {
-            YH_HIP(hipEventRecord(g_fork, mainst));
-            YH_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+            if (auto_side) {     // weight-gradient work: fork right here, after the op that produced dY
+                YH_HIP(hipEventRecord(g_fork, mainst));
+                YH_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+            }
             rc = run_one(ops[k], (void *)g_side);
             forked = true;
         } else {

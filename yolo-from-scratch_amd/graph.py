@@ -15,6 +15,7 @@ Design points (all about HBM traffic, the bound for this small-channel network):
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -93,6 +94,7 @@ class ConvRec:
     ldwf: int = 0
     ldwb: int = 0
     need_dx: bool = True
+    lane: int = 0
 
 
 @dataclass
@@ -100,6 +102,13 @@ class PoolRec:
     x: View
     out: View
     arg: Optional[torch.Tensor] = None
+    lane: int = 0
+
+
+@dataclass
+class SyncRec:
+    """fork (side lane may start) / join (main lane waits for the side lane) marker in the forward order"""
+    kind: str
 
 
 class Plan:
@@ -113,6 +122,7 @@ class Plan:
         self.outputs: List[Tuple[View, str]] = []       # (view, "nhwc_heads" | "nchw")
         self.input = self.new_buffer(self.B, self.Himg, self.Wimg, _rup4(self.Cimg), "input")
         self.generation = 0
+        self.lane = 0                      # lane given to records traced from now on (see side_lane())
         self.fwd_ops = self.bwd_ops = None
         self.param_ptrs: List[int] = []
 
@@ -144,13 +154,34 @@ class Plan:
         if residual is not None and (residual.H, residual.W, residual.C) != (Ho, Wo, cout):
             raise ValueError("residual shape mismatch")
         self.recs.append(ConvRec(x, out, conv.weight, conv.bias, bn, k, s, residual, upsample, cin=x.C, cout=cout,
-                                 Ho=Ho, Wo=Wo))
+                                 Ho=Ho, Wo=Wo, lane=self.lane))
         return out
+
+    # independent sub-graphs: `with plan.side_lane():` traces the enclosed layers onto the side stream;
+    # a fork marker is emitted on entry (the side lane sees everything traced before), the join is emitted
+    # by `join()` (or implicitly at the end of the op list)
+    def side_lane(self):
+        plan = self
+
+        enabled = os.environ.get("YH_SIDE_LANES", "1") != "0"      # tuning knob
+
+        class _Ctx:
+            def __enter__(self_inner):
+                if enabled:
+                    plan.recs.append(SyncRec("fork"))
+                    plan.lane = 1
+
+            def __exit__(self_inner, *exc):
+                plan.lane = 0
+        return _Ctx()
+
+    def join(self):
+        self.recs.append(SyncRec("join"))
 
     def pool5(self, x: View, out: View) -> View:
         if x.C % 4 or (x.H, x.W, x.C) != (out.H, out.W, out.C):
             raise ValueError("pool5: shape mismatch or channels not a multiple of 4")
-        self.recs.append(PoolRec(x, out))
+        self.recs.append(PoolRec(x, out, lane=self.lane))
         return out
 
     def mark_output(self, v: View, kind: str):
@@ -179,6 +210,10 @@ class Plan:
         packs: List[tuple] = []                # one descriptor per conv for the single pack launch
         folds: List[tuple] = []                # inference: BN folded into the packed weights
         for r in self.recs:
+            if isinstance(r, SyncRec):
+                fwd.append(_op(L.OP_FORK if r.kind == "fork" else L.OP_JOIN))
+                continue
+            ln = r.lane
             if isinstance(r, ConvRec):
                 kk = r.k * r.k
                 r.ldwf, r.ldwb = _rup4(r.cout), _rup4(r.cin)
@@ -196,7 +231,7 @@ class Plan:
                     fwd.append(_op(L.OP_CONV_FWD_FUSED,
                                    p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()],
                                    i=[r.x.ld, r.ldwf, r.residual.ld if r.residual else 0, r.out.ld, r.x.B, r.x.H, r.x.W,
-                                      r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)]))
+                                      r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], lane=ln))
                     continue
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
                 r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
@@ -216,7 +251,7 @@ class Plan:
                 fwd.append(_op(L.OP_CONV_FWD,
                                p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                   r.part if r.bn is not None else None],
-                               i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s]))
+                               i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
                 if r.bn is not None:
                     track = r.bn.track_running_stats and r.bn.running_mean is not None
                     mom = r.bn.momentum if r.bn.momentum is not None else 0.1
@@ -224,15 +259,15 @@ class Plan:
                                    p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
                                       r.bn.running_var if track else None, r.coef,
                                       r.bn.num_batches_tracked if track else None],
-                                   i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M]))
+                                   i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M], lane=ln))
                     fwd.append(_op(L.OP_BN_SILU_FWD,
                                    p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
                                    i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
-                                      int(r.upsample)], l=[M]))
+                                      int(r.upsample)], l=[M], lane=ln))
             else:
                 r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
                 fwd.append(_op(L.OP_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
-                               i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C]))
+                               i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C], lane=ln))
         if folds:
             import struct
             blob = b"".join(struct.pack("<QQQQQQQQiiiiif", *d) for d in folds)
@@ -280,6 +315,8 @@ class Plan:
         ops: List[L.YhOp] = []
         self.grad_ready: Dict[int, int] = {}     # id(param) -> number of backward ops after which its grad is final
         for r in reversed(self.recs):
+            if isinstance(r, SyncRec):
+                continue
             if isinstance(r, PoolRec):
                 dst, acc = self._grad_target(r.x)
                 if not acc:
@@ -341,9 +378,10 @@ def _addr(x) -> Optional[int]:
     return x.data_ptr()
 
 
-def _op(kind: int, p=(), i=(), f=(), l=()) -> L.YhOp:
+def _op(kind: int, p=(), i=(), f=(), l=(), lane: int = 0) -> L.YhOp:
     o = L.YhOp()
     o.kind = kind
+    o.lane = lane
     for n, v in enumerate(p):
         o.p[n] = _addr(v)
     for n, v in enumerate(i):

@@ -12,6 +12,7 @@ Interface parity: NCHW fp32 in; ConvBlock/C3/Bottleneck/SPPF return NCHW, YOLO r
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -210,13 +211,24 @@ class C3(HipModule):
         self.bottlenecks = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut) for _ in range(n)])
         self._hidden = hidden
 
-    def _emit(self, g, x, out=None):
+    def _emit(self, g, x, out=None, side_branch=False):
+        """side_branch: run the conv2 branch on the side lane next to conv1 -> bottlenecks (only where no other
+        long-running side-lane work is pending, since the join waits for everything on that lane)."""
         hid = self._hidden
         if hid % 4:
             raise NotImplementedError("C3 hidden channels must be a multiple of 4 on the HIP path")
         Ho, Wo = x.H, x.W
         cat = g.new_buffer(x.B, Ho, Wo, 2 * hid, "c3cat")
         nb = len(self.bottlenecks)
+        if side_branch:
+            # conv2 only needs x: trace it first on the side lane, then the main chain, then join
+            with g.side_lane():
+                self.conv2._emit(g, x, out=cat.view(hid, hid))
+            a = self.conv1._emit(g, x, out=cat.view(0, hid) if nb == 0 else None)
+            for i, b in enumerate(self.bottlenecks):
+                a = b._emit(g, a, out=cat.view(0, hid) if i == nb - 1 else None)
+            g.join()
+            return self.conv3._emit(g, cat.view(), out=out)
         a = self.conv1._emit(g, x, out=cat.view(0, hid) if nb == 0 else None)
         for i, b in enumerate(self.bottlenecks):
             a = b._emit(g, a, out=cat.view(0, hid) if i == nb - 1 else None)
@@ -341,13 +353,14 @@ class YOLO(HipModule):
         x = g.conv(x, self.stem[0], self.stem[1])
         x = g.conv(x, self.stem[3], self.stem[4])
         bp3, bp4, bp5 = self.backbone_p3, self.backbone_p4, self.backbone_p5
-        x = bp3[0]._emit(g, x)
+        sb = os.environ.get("YH_C3_SIDE", "1") != "0"     # tuning knob
+        x = bp3[0]._emit(g, x, side_branch=sb)
         x = g.conv(x, bp3[1], bp3[2])
-        p3 = bp3[4]._emit(g, x)
+        p3 = bp3[4]._emit(g, x, side_branch=sb)
         x = g.conv(p3, bp4[0], bp4[1])
-        p4 = bp4[3]._emit(g, x)
+        p4 = bp4[3]._emit(g, x, side_branch=sb)
         x = g.conv(p4, bp5[0], bp5[1])
-        x = bp5[3]._emit(g, x)
+        x = bp5[3]._emit(g, x, side_branch=sb)
         # concat buffers: [p4_down | p5_backbone], [p5_up | p4_lateral], [p4_up | p3_lateral], [p3_down | p4_fpn]
         cat_pan5 = g.new_buffer(B, H5, W5, c4 + c5, "cat_pan5")
         cat_fpn4 = g.new_buffer(B, H4, W4, 2 * c4, "cat_fpn4")
@@ -357,16 +370,29 @@ class YOLO(HipModule):
         self.lateral_p4._emit(g, p4, out=cat_fpn4.view(c4, c4))
         self.lateral_p3._emit(g, p3, out=cat_fpn3.view(c3, c3))
         self.reduce_p5_for_p4._emit(g, p5, out=cat_fpn4.view(0, c4), upsample=True)
-        p4f = self.merge_p4._emit(g, cat_fpn4.view(), out=cat_pan4.view(c3, c4))
+        p4f = self.merge_p4._emit(g, cat_fpn4.view(), out=cat_pan4.view(c3, c4), side_branch=sb)
         self.reduce_p4_for_p3._emit(g, p4f, out=cat_fpn3.view(0, c3), upsample=True)
-        p3f = self.merge_p3._emit(g, cat_fpn3.view())
+        p3f = self.merge_p3._emit(g, cat_fpn3.view(), side_branch=sb)
+
+        def head(feat, hd):
+            h = hd[1]._emit(g, hd[0]._emit(g, feat))
+            return g.conv(h, hd[2], None)
+
+        # The P3 and P4 heads (one third of the forward FLOPs) depend only on p3_fpn / p4_panet: they run on the
+        # side lane next to the PANet chain, so their HBM-bound BatchNorm passes and tail rounds overlap the
+        # neck's MFMA work and vice versa.  Outputs are registered in the reference's order (P3, P4, P5).
+        with g.side_lane():
+            out3 = head(p3f, self.head_p3)
         self.downsample_p3_to_p4._emit(g, p3f, out=cat_pan4.view(0, c3))
         p4n = self.panet_merge_p4._emit(g, cat_pan4.view())
+        with g.side_lane():
+            out4 = head(p4n, self.head_p4)
         self.downsample_p4_to_p5._emit(g, p4n, out=cat_pan5.view(0, c4))
         p5n = self.panet_merge_p5._emit(g, cat_pan5.view())
-        for feat, hd in ((p3f, self.head_p3), (p4n, self.head_p4), (p5n, self.head_p5)):
-            h = hd[1]._emit(g, hd[0]._emit(g, feat))
-            g.mark_output(g.conv(h, hd[2], None), "nhwc_heads")
+        out5 = head(p5n, self.head_p5)
+        g.join()
+        for o in (out3, out4, out5):
+            g.mark_output(o, "nhwc_heads")
 
     def _package(self, outs):
         return outs
