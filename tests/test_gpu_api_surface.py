@@ -1,0 +1,101 @@
+"""Drop-in behaviour of the reference's public surface on the HIP path: the same calls the
+reference's own tests make -- module shapes at several sizes, train_epoch with a user-constructed torch optimizer
+and with the fused HipAdam, eval_epoch metric ranges, predict's tuple format -- on a tiny synthetic dataset."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+pytestmark = pytest.mark.gpu
+
+
+def api():
+    import yolo_from_scratch_amd as y
+    return y
+
+
+@pytest.fixture(scope="module")
+def dataset_dir(tmp_path_factory):
+    from PIL import Image
+    root = tmp_path_factory.mktemp("ds")
+    (root / "train" / "images").mkdir(parents=True)
+    (root / "train" / "labels").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 255, (200, 260, 3), dtype=np.uint8)).save(root / "train" / "images" / f"im{i}.jpg")
+        with open(root / "train" / "labels" / f"im{i}.txt", "w") as f:
+            for _ in range(int(rng.integers(1, 4))):
+                w, h = rng.uniform(0.1, 0.5, 2)
+                f.write(f"{int(rng.integers(0, 2))} {rng.uniform(0.3, 0.7):.4f} {rng.uniform(0.3, 0.7):.4f} {w:.4f} {h:.4f}\n")
+    return root
+
+
+def test_block_and_model_shapes():
+    y = api()
+    dev = torch.device("cuda")
+    assert y.ConvBlock(3, 16, 3, 1, 1).to(dev)(torch.randn(2, 3, 32, 32, device=dev)).shape == (2, 16, 32, 32)
+    assert y.ConvBlock(16, 32, 3, 2, 1).to(dev)(torch.randn(1, 16, 32, 32, device=dev)).shape == (1, 32, 16, 16)
+    assert y.Bottleneck(16, 16).to(dev)(torch.randn(2, 16, 8, 8, device=dev)).shape == (2, 16, 8, 8)
+    assert y.C3(32, 64, n=2).to(dev)(torch.randn(2, 32, 8, 8, device=dev)).shape == (2, 64, 8, 8)
+    assert y.SPPF(32, 32).to(dev)(torch.randn(2, 32, 8, 8, device=dev)).shape == (2, 32, 8, 8)
+    for S, nc, B in ((512, 1, 1), (320, 3, 2), (1024, 1, 1)):
+        m = y.YOLO(num_classes=nc, img_size=S).to(dev)
+        outs = m(torch.randn(B, 3, S, S, device=dev))
+        assert [tuple(o.shape) for o in outs] == [(B, S // s, S // s, 3, 5 + nc) for s in (8, 16, 32)]
+        assert all(o.is_contiguous() and torch.isfinite(o).all() for o in outs)
+    with pytest.raises(AssertionError):
+        y.YOLO(img_size=100).to(dev)(torch.randn(1, 3, 100, 100, device=dev))      # not a multiple of 32 (train.py:606)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_train_epoch_eval_epoch_predict(dataset_dir, fused):
+    y = api()
+    dev = torch.device("cuda")
+    nc, S = 2, 320
+    ds = y.YOLODataset(str(dataset_dir / "train" / "images"), num_classes=nc, img_size=S)
+    assert len(ds) == 6
+    img, tg = ds[0]
+    assert img.shape == (3, S, S) and [t.shape for t in tg] == [(S // s, S // s, 3, 5 + nc) for s in (8, 16, 32)]
+    assert sum(int((t[..., 4] > 0.5).sum()) for t in tg) >= 1
+    loader = DataLoader(ds, batch_size=3, shuffle=False, collate_fn=y.yolo_collate_fn)
+    torch.manual_seed(0)
+    model = y.YOLO(num_classes=nc, img_size=S).to(dev)
+    before = [p.detach().clone() for p in model.parameters()]
+    opt = y.HipAdam(model, lr=1e-3) if fused else torch.optim.Adam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, y.get_lr_lambda(1, 3, 1e-3, 1e-5))
+    res = y.train_epoch(model, loader, opt, dev, nc)
+    sched.step()
+    res2 = y.train_epoch(model, loader, opt, dev, nc)
+    assert len(res) == 4 and all(isinstance(v, float) and np.isfinite(v) and v >= 0 for v in res + res2)
+    assert res[0] < 1e6 and any(not torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+    loss, p, r, f1 = y.eval_epoch(model, loader, dev, nc)
+    assert np.isfinite(loss) and 0 <= p <= 100 and 0 <= r <= 100 and 0 <= f1 <= 100
+    assert all(q.grad is None or torch.isfinite(q.grad).all() for q in model.parameters())
+    model.initialize_detection_biases(prior=0.3)
+    dets = y.predict(model, str(dataset_dir / "train" / "images" / "im0.jpg"), dev, nc, conf_threshold=0.25, iou_threshold=0.4)
+    assert isinstance(dets, list)
+    for d in dets:
+        assert len(d) == 6 and isinstance(d[5], int) and 0 <= d[5] < nc
+    # state-dict round trip (reference quirk Q5 fixed: grid buffers are contiguous)
+    m2 = y.YOLO(num_classes=nc, img_size=S)
+    m2.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+
+
+def test_autograd_path_equals_fused_path():
+    """Same seeded model and batch: loss.backward() through the autograd nodes and the fused trainer give the same
+    gradients (bitwise: they replay the same op lists)."""
+    y = api()
+    dev = torch.device("cuda")
+    x = torch.rand(2, 3, 320, 320, generator=torch.Generator().manual_seed(3)).to(dev)
+    tg = [t.to(dev) for t in y.synthetic_targets(2, 1, 320, 6, 9)]
+    torch.manual_seed(1)
+    a = y.YOLO(num_classes=1, img_size=320).to(dev)
+    loss = y.yolo_loss_multiscale(a(x), tg, a.anchors, 1)[0]
+    loss.backward()
+    torch.manual_seed(1)
+    b = y.YOLO(num_classes=1, img_size=320).to(dev)
+    tr = y.HipTrainer(b, lr=0.0, max_norm=None)
+    out = tr.step(x, tg)
+    assert abs(float(out[0]) - float(loss)) <= 1e-6 * abs(float(loss))
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa.grad, pb.grad), n

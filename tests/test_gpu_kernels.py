@@ -223,3 +223,47 @@ def test_clip_adam_matches_oracle(n, world):
         assert rel_err(g, gr) < 1e-6            # clipped gradient is written back, as clip_grad_norm_ does
         assert rel_err(p, pr) < 1e-6 and rel_err(m, mr) < 1e-6 and rel_err(v, vr) < 1e-6
         g = (torch.randn(npad) * 3).cuda()
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,res,up,act", [(16, 32, 3, 1, True, False, True), (32, 16, 1, 1, False, True, True),
+                                                    (8, 20, 1, 1, False, False, False), (64, 64, 3, 2, False, False, True)])
+def test_fused_inference_conv_with_folded_bn(Cin, Cout, k, s, res, up, act):
+    """yh_pack_fold_multi + yh_conv_fwd_fused == eval-mode conv -> BatchNorm -> SiLU (+residual) (+x2 nearest)."""
+    import struct
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, H, W = 2, 12, 10
+    torch.manual_seed(Cin * Cout + k)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout) * 0.1
+    gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.2
+    rm, rv = torch.randn(Cout) * 0.3, torch.rand(Cout) + 0.5
+    y = F.conv2d(x.double(), w.double(), bias.double(), s, k // 2)
+    if act:
+        y = F.silu(F.batch_norm(y, rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5))
+    Ho, Wo = y.shape[2], y.shape[3]
+    r = torch.randn(B, Cout, Ho, Wo) if res else None
+    if res:
+        y = y + r.double()
+    if up:
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+    dev = "cuda"
+    ldwf = rup4(Cout)
+    wd, bd = w.to(dev), bias.to(dev)
+    g_, b_, rm_, rv_ = gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev)
+    wf = torch.empty(k * k * Cin * ldwf, device=dev)
+    fb = torch.empty(Cout, device=dev)
+    rec = struct.pack("<QQQQQQQQiiiiif", wd.data_ptr(), bd.data_ptr(), g_.data_ptr() if act else 0, b_.data_ptr() if act else 0,
+                      rm_.data_ptr() if act else 0, rv_.data_ptr() if act else 0, wf.data_ptr(), fb.data_ptr(), Cout, Cin, k * k,
+                      Cin, ldwf, 1e-5)
+    tab = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+    L.check(lib.yh_pack_fold_multi(tab.data_ptr(), 1, st))
+    xg = nhwc(x)
+    rg = nhwc(r) if res else None
+    f = 2 if up else 1
+    out = torch.empty(B, Ho * f, Wo * f, Cout, device=dev)
+    L.check(lib.yh_conv_fwd_fused(xg.data_ptr(), Cin, wf.data_ptr(), ldwf, fb.data_ptr(), rg.data_ptr() if res else None, Cout,
+                                  out.data_ptr(), Cout, B, H, W, Cin, Cout, k, s, int(act), int(up), st))
+    assert rel_err(out.permute(0, 3, 1, 2), y) < 1e-4
