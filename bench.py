@@ -43,6 +43,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
     st = torch.cuda.current_stream(dev).cuda_stream
     conv_ms, n_launch = 0.0, 0
     per_kind = {}
+    L.lib().yh_set_overlap(0)        # every launch on the timed stream while instrumenting
     for _ in range(steps):
         trainer.model._load_input(plan, imgs)
         evs = []
@@ -60,6 +61,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
+    L.lib().yh_set_overlap(1)
     return conv_ms / steps, n_launch // steps, {k: v / steps for k, v in per_kind.items()}
 
 

@@ -16,20 +16,19 @@ _OBJ_W = (4.0, 1.0, 0.4)          # train.py:865
 _W_BOX, _W_CLS = 0.05, 0.5        # train.py:879
 LOSS_IMG_SIZE = 640.0             # yolo_loss decodes with the default img_size (train.py:796, quirk Q1)
 
-_anchor_cache = {}
-
-
 def _host_anchors(a) -> List[float]:
-    """(3,2) anchor tensor -> 6 host floats (cached: anchors are constant buffers)."""
+    """(3,2) anchor tensor -> 6 host floats.  The kernels take anchors by value (HOST array), so a device
+    tensor costs one read-back; the copy is cached ON THE TENSOR OBJECT (model buffers live as long as the
+    model) together with its version counter -- never keyed by address, which the allocator recycles."""
     if isinstance(a, torch.Tensor):
-        key = (a.data_ptr(), a._version, str(a.device))
-        hit = _anchor_cache.get(key)
-        if hit is None:
-            hit = [float(v) for v in a.detach().reshape(-1).tolist()]
-            if len(_anchor_cache) > 64:
-                _anchor_cache.clear()
-            _anchor_cache[key] = hit
-        return hit
+        hit = getattr(a, "_yh_host", None)
+        if hit is None or hit[0] != a._version:
+            hit = (a._version, [float(v) for v in a.detach().reshape(-1).tolist()])
+            try:
+                a._yh_host = hit
+            except AttributeError:
+                pass
+        return hit[1]
     return [float(v) for row in a for v in row]
 
 
