@@ -65,10 +65,23 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
     return conv_ms / steps, n_launch // steps, {k: v / steps for k, v in per_kind.items()}
 
 
+def host_cores():
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(batch=8, steps=3):
     """The CPU oracle's training step (same math on stock torch CPU ops) on a bounded sample."""
     from oracle import yolo_oracle as orc
     import yolo_from_scratch_amd as y
+    torch.set_num_threads(host_cores())       # oversubscribing the quota is several times slower
     torch.manual_seed(0)
     m = y.YOLO(num_classes=NC, img_size=IMG)
     P = {k: v.clone() for k, v in m.state_dict().items()}
