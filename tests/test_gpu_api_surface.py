@@ -99,3 +99,54 @@ def test_autograd_path_equals_fused_path():
     assert abs(float(out[0]) - float(loss)) <= 1e-6 * abs(float(loss))
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(pa.grad, pb.grad), n
+
+
+@pytest.mark.parametrize("size,S,B,nc", [("n", 416, 1, 1), ("m", 224, 2, 2), ("s", 352, 3, 1), ("l", 160, 1, 1), ("x", 96, 2, 3)])
+def test_other_sizes_and_ragged_shapes_match_oracle(size, S, B, nc):
+    """Other width/depth multipliers (24/48/96... channel counts, 2 Bottlenecks per C3 for 'm'), odd grid sizes
+    (13, 11, 7 cells: ragged GEMM tiles and row segments) and batch 1, one fused step vs the CPU oracle."""
+    from oracle import yolo_oracle as orc
+    y = api()
+    wm, dm = y.YOLO_SIZES[size]
+    torch.manual_seed(4)
+    m = y.YOLO(num_classes=nc, img_size=S, width_mult=wm, depth_mult=dm)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(8))
+    targets = y.synthetic_targets(B, nc, S, 5, 31)
+    m = m.cuda()
+    tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
+    out = tr.step(x.cuda(), [t.cuda() for t in targets]).cpu().numpy()
+    for n in names:
+        P[n].requires_grad_(True)
+    ref = orc.loss_multiscale(orc.forward(P, x, nc, True), targets, orc.anchors_of(P), nc)
+    np.testing.assert_allclose(out[:4], [float(v) for v in ref], rtol=1e-4, atol=1e-6)
+    ref[0].backward()
+    total, coef = orc.clip_coef([P[n].grad for n in names], 10.0)
+    assert abs(float(tr.norm) - total) <= 5e-4 * total
+    params = dict(m.named_parameters())
+    for n in names[::7]:
+        if n.endswith(".bias") and not ("bn" in n or n.startswith("head")):
+            continue                                      # conv biases in front of BN: noise gradients (Q2)
+        r = P[n].grad * coef
+        assert float((params[n].grad.cpu() - r).abs().max()) <= 4e-3 * float(r.abs().max()) + 1e-8, n
+
+
+def test_no_object_batch_and_loss_identities():
+    """yolo_loss with no positives: bbox == 0, cls == 0, obj > 0 (reference tests/test_loss.py:91-109), and the
+    weight identity total == 0.05*b + 1.0*o + 0.5*c (111-129); gradients stay finite."""
+    y = api()
+    dev = torch.device("cuda")
+    anc = torch.tensor([[30., 61.], [62., 45.], [59., 119.]], device=dev)
+    pred = torch.randn(2, 13, 13, 3, 6, device=dev, requires_grad=True)
+    tgt = torch.zeros(2, 13, 13, 3, 6, device=dev)
+    tot, b, o, c = y.yolo_loss(pred, tgt, anc, 1)
+    assert b.item() == 0.0 and c.item() == 0.0 and o.item() > 0
+    tgt[0, 3, 4, 1] = torch.tensor([0.3, 0.3, 0.2, 0.25, 1.0, 1.0], device=dev)
+    tot, b, o, c = y.yolo_loss(pred, tgt, anc, 1)
+    assert abs(tot.item() - (0.05 * b.item() + 1.0 * o.item() + 0.5 * c.item())) < 1e-5 and b.item() > 0
+    tot.backward()
+    assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().sum()) > 0
+    dec = y.decode_predictions(pred.detach(), anc)
+    assert dec.shape == pred.shape and torch.equal(dec[..., 4:], pred.detach()[..., 4:])
+    assert float(dec[..., 2:4].min()) > 0 and -0.1 < float(dec[..., 0].min()) and float(dec[..., 0].max()) < 1.1

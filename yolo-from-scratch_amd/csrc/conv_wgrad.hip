@@ -254,7 +254,8 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
         g.Ho = (Hi + 2 * g.pad - k) / s + 1; g.Wo = (Wi + 2 * g.pad - k) / s + 1;
     }
     // slab shape: keep <= 36 tiles (9 per wave) and LDS modest
-    if (k == 1) { g.CIT = Cin >= 128 ? 128 : Cin; g.COT = Cout >= 128 ? 128 : (Cout + 3) / 4 * 4; }
+    // column tiles per slab must be 1, 2 or 4 (wave ownership): COT is 128, 64 or the whole (<= 64) channel count
+    if (k == 1) { g.CIT = Cin >= 128 ? 128 : Cin; g.COT = Cout >= 128 ? 128 : (Cout > 64 ? 64 : (Cout + 3) / 4 * 4); }
     else {
         static const int cit3 = getenv("YH_WGRAD_CIT3") ? atoi(getenv("YH_WGRAD_CIT3")) : 32;   // tuning knob
         g.CIT = (s == 2) ? (Cin >= 32 ? 32 : Cin) : (Cin >= cit3 ? cit3 : Cin);
@@ -266,8 +267,10 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     {   // MFMA shape: cycles per pixel = tiles32 * 64/2 vs tiles16 * 32/4
         int t32 = cdiv(k * k * g.CIT, 32) * cdiv(g.COT, 32), t16 = cdiv(k * k * g.CIT, 16) * cdiv(g.COT, 16);
         static const int force = getenv("YH_WGRAD_MT") ? atoi(getenv("YH_WGRAD_MT")) : 0;   // tuning knob
-        g.MT = (t16 < 4 * t32 && t16 <= 20) ? 16 : 32;
-        if (force == 16 && t16 <= 20) g.MT = 16;
+        const int ot16 = cdiv(g.COT, 16);
+        const bool ok16 = t16 <= 20 && (ot16 == 1 || ot16 == 2 || ot16 == 4);
+        g.MT = (t16 < 4 * t32 && ok16) ? 16 : 32;
+        if (force == 16 && ok16) g.MT = 16;
         if (force == 32) g.MT = 32;
         int RT = cdiv(k * k * g.CIT, g.MT), OT = cdiv(g.COT, g.MT);
         if (OT != 1 && OT != 2 && OT != 4) return YH_E_UNSUPPORTED;
