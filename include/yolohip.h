@@ -134,6 +134,12 @@ int yh_yolo_loss(const float *const pred[3], const float *const target[3], float
                  const float *anchors, const int grid[3], int B, int nc, float loss_img_size, const float *loss_w,
                  const float *grad_w, float *out, float *ws, void *stream);
 int64_t yh_loss_ws(const int grid[3], int B);
+/* eval_epoch's detection metric (train.py:990-1024): counts[0..3) += TP, FP, FN over all cells of the three
+ * scales -- same cell, same anchor; sigmoid(obj) > conf_thr vs target obj > conf_thr; a matched pair is a TP when
+ * compute_box_iou (centre format, eps 1e-6) > iou_thr, else an FP.  counts is a DEVICE int64[3] the caller zeroes
+ * (integer atomics: order-independent).  decode_img_size: the reference decodes with its default 640 here too. */
+int yh_eval_counts(const float *const pred[3], const float *const target[3], const float *anchors, const int grid[3],
+                   int B, int nc, float decode_img_size, float conf_thr, float iou_thr, int64_t *counts, void *stream);
 /* Standalone pieces of the same math for the reference's public functions (anchors3x2: HOST).
  * yh_ciou: ws >= 2*ceil(N/256) floats, 8-byte aligned; N must be > 0. */
 int yh_decode(const float *raw, float *out, const float *anchors3x2, int B, int GH, int GW, int nc,

@@ -351,11 +351,48 @@ def gen_assign():
     save("assign", **out)
 
 
+def gen_evalcounts():
+    """f-2: the grid-cell TP/FP/FN counting of the reference's eval_epoch (train.py:990-1024), run by the
+    reference itself on recorded predictions (a stub module returns them; the loop is the reference's)."""
+    out = {}
+    for tag, nc, S, seed in (("nc1", 1, 320, 31), ("nc3", 3, 256, 32)):
+        torch.manual_seed(seed)
+        grids = [S // 8, S // 16, S // 32]
+        targets = orc.assign_targets(orc.synthetic_boxes(2, nc, S, 10, seed), S, nc)
+        preds = []
+        for g_, t in zip(grids, targets):
+            p = torch.randn(2, g_, g_, 3, 5 + nc) * 1.5
+            # make a good share of the positive cells confident and roughly aligned so that TP/FP/FN all occur
+            pos = t[..., 4] > 0.5
+            p[..., 4][pos] = torch.randn(int(pos.sum())) * 2.0 + 1.0
+            preds.append(p)
+
+        class Stub(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.anchors = ref.YOLO(num_classes=nc, img_size=S).anchors
+                self.grid_size_p3, self.grid_size_p4, self.grid_size_p5 = grids
+
+            def forward(self, x):
+                return [p.clone() for p in preds]
+
+        loader = [(torch.zeros(2, 3, S, S), [[t[b] for t in targets] for b in range(2)])]
+        for conf, iou in ((0.5, 0.5), (0.3, 0.2)):
+            loss, p_, r_, f1 = ref.eval_epoch(Stub(), loader, torch.device("cpu"), nc, iou_threshold=iou, conf_threshold=conf)
+            out[f"{tag}/c{conf}_i{iou}"] = np.array([loss, p_, r_, f1], np.float64)
+        for s_, (p, t) in enumerate(zip(preds, targets)):
+            out[f"{tag}/pred{s_}"] = npy(p)
+            out[f"{tag}/pos_idx{s_}"] = npy((t[..., 4] > 0.5).nonzero())
+            out[f"{tag}/pos_val{s_}"] = npy(t[t[..., 4] > 0.5])
+        out[f"{tag}/meta"] = np.array([nc, S])
+    save("evalcounts", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = {
         "blocks": gen_blocks, "decode": gen_decode, "ciou": gen_ciou, "loss": gen_loss,
-        "nms": gen_nms, "candidates": gen_candidates, "assign": gen_assign,
+        "nms": gen_nms, "candidates": gen_candidates, "assign": gen_assign, "evalcounts": gen_evalcounts,
         "model_nc1": lambda: gen_model("model_nc1", 1, 640, 2),
         "model_nc3": lambda: gen_model("model_nc3", 3, 320, 2),
     }

@@ -150,3 +150,35 @@ def test_no_object_batch_and_loss_identities():
     dec = y.decode_predictions(pred.detach(), anc)
     assert dec.shape == pred.shape and torch.equal(dec[..., 4:], pred.detach()[..., 4:])
     assert float(dec[..., 2:4].min()) > 0 and -0.1 < float(dec[..., 0].min()) and float(dec[..., 0].max()) < 1.1
+
+
+@pytest.mark.parametrize("tag", ["nc1", "nc3"])
+def test_eval_epoch_counts_match_reference_loop(tag):
+    """eval_epoch's grid-cell precision / recall / F1 (one HIP kernel) against the numbers the
+    reference's own 4-deep Python loop produced on the same recorded predictions (tests/golden/evalcounts.npz)."""
+    from conftest import load_golden
+    y = api()
+    g = load_golden("evalcounts")
+    nc, S = (int(v) for v in g[f"{tag}/meta"])
+    dev = torch.device("cuda")
+    grids = [S // 8, S // 16, S // 32]
+    preds = [torch.from_numpy(g[f"{tag}/pred{s}"]).to(dev) for s in range(3)]
+    targets = [torch.zeros(2, gs, gs, 3, 5 + nc) for gs in grids]
+    for s in range(3):
+        for (b, i, j, a), v in zip(g[f"{tag}/pos_idx{s}"], g[f"{tag}/pos_val{s}"]):
+            targets[s][b, i, j, a] = torch.from_numpy(v)
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.anchors = [torch.tensor(a, dtype=torch.float32, device=dev) for a in y.DEFAULT_ANCHORS]
+
+        def forward(self, x):
+            return [p.clone() for p in preds]
+
+    loader = [(torch.zeros(2, 3, S, S), [[t[b] for t in targets] for b in range(2)])]
+    for conf, iou in ((0.5, 0.5), (0.3, 0.2)):
+        got = y.eval_epoch(Stub(), loader, dev, nc, iou_threshold=iou, conf_threshold=conf)
+        want = g[f"{tag}/c{conf}_i{iou}"]
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-4)
+        np.testing.assert_allclose(got[1:], want[1:], rtol=1e-9, atol=1e-12)     # integer counts -> identical ratios

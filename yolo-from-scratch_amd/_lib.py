@@ -61,6 +61,7 @@ _SIGS = {
     "yh_maxpool5_bwd": (i32, [c_fp, i32, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_yolo_loss": (i32, [_PP, _PP, _PP, C.POINTER(f32), _IP, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp, c_fp]),
     "yh_loss_ws": (i64, [_IP, i32]),
+    "yh_eval_counts": (i32, [_PP, _PP, C.POINTER(f32), _IP, i32, i32, f32, f32, f32, c_fp, c_fp]),
     "yh_decode": (i32, [c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
     "yh_decode_bwd": (i32, [c_fp, c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
     "yh_ciou": (i32, [c_fp, c_fp, c_fp, i64, f32, f32, c_fp, c_fp, c_fp]),

@@ -288,6 +288,55 @@ __global__ void ciou_final_kernel(const double *__restrict__ part, int nblk, int
     }
 }
 
+// ---- eval_epoch's same-cell / same-anchor TP, FP, FN counting (train.py:990-1024) ------------------------
+struct EvalArgs {
+    const float *pred[3], *tgt[3];
+    float anchors[18];
+    int grid[3];
+    int64_t cells[3];
+    int blk_begin[4];
+    int nc;
+    float img, conf, iou;
+    unsigned long long *counts;   // [3] = tp, fp, fn
+};
+
+__global__ void eval_counts_kernel(const EvalArgs a) {
+    const int s = blockIdx.x >= a.blk_begin[2] ? 2 : (blockIdx.x >= a.blk_begin[1] ? 1 : 0);
+    const int64_t cell = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256 + threadIdx.x;
+    int tp = 0, fp = 0, fn = 0;
+    if (cell < a.cells[s]) {
+        const int ch = 5 + a.nc, G = a.grid[s];
+        const float *p = a.pred[s] + cell * ch, *t = a.tgt[s] + cell * ch;
+        const bool pobj = yh_sigmoid(p[4]) > a.conf, tobj = t[4] > a.conf;
+        if (pobj && tobj) {
+            int an = (int)(cell % 3);
+            int64_t q = cell / 3;
+            int j = (int)(q % G), i = (int)((q / G) % G);
+            // decode_predictions(pred, anchors) with the default img_size (train.py:993)
+            float bx = ((yh_sigmoid(p[0]) * 2.0f - 0.5f) + (float)j) / (float)G;
+            float by = ((yh_sigmoid(p[1]) * 2.0f - 0.5f) + (float)i) / (float)G;
+            float tw = 2.0f * yh_sigmoid(p[2]), th = 2.0f * yh_sigmoid(p[3]);
+            float bw = (a.anchors[(s * 3 + an) * 2 + 0] / a.img) * (tw * tw);
+            float bh = (a.anchors[(s * 3 + an) * 2 + 1] / a.img) * (th * th);
+            // compute_box_iou (train.py:928-958): centre format, eps 1e-6 in the denominator
+            float ax1 = bx - bw / 2, ax2 = bx + bw / 2, ay1 = by - bh / 2, ay2 = by + bh / 2;
+            float cx1 = t[0] - t[2] / 2, cx2 = t[0] + t[2] / 2, cy1 = t[1] - t[3] / 2, cy2 = t[1] + t[3] / 2;
+            float iw = fmaxf(fminf(ax2, cx2) - fmaxf(ax1, cx1), 0.f), ih = fmaxf(fminf(ay2, cy2) - fmaxf(ay1, cy1), 0.f);
+            float inter = iw * ih;
+            float uni = (ax2 - ax1) * (ay2 - ay1) + (cx2 - cx1) * (cy2 - cy1) - inter;
+            if (inter / (uni + 1e-6f) > a.iou) tp = 1; else fp = 1;
+        } else if (pobj) {
+            fp = 1;
+        } else if (tobj) {
+            fn = 1;
+        }
+    }
+    unsigned long long m;
+    m = __ballot(tp); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counts[0], (unsigned long long)__popcll(m));
+    m = __ballot(fp); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counts[1], (unsigned long long)__popcll(m));
+    m = __ballot(fn); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counts[2], (unsigned long long)__popcll(m));
+}
+
 int fill_args(LossArgs &a, const float *const pred[3], const float *const target[3], float *const dpred[3],
               const float *anchors, const int grid[3], int B, int nc, float img, const float *loss_w,
               const float *grad_w, float *out, float *ws) {
@@ -383,5 +432,28 @@ extern "C" int yh_ciou(const float *pred, const float *tgt, float *dpred, int64_
     YH_CHECK_LAUNCH("ciou");
     hipLaunchKernelGGL(ciou_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)ws, nblk, N, loss_out);
     YH_CHECK_LAUNCH("ciou_final");
+    return 0;
+}
+
+extern "C" int yh_eval_counts(const float *const pred[3], const float *const target[3], const float *anchors,
+                              const int grid[3], int B, int nc, float decode_img_size, float conf_thr, float iou_thr,
+                              int64_t *counts, void *stream) {
+    YH_REQUIRE(pred && target && anchors && grid && counts && B > 0 && nc >= 0, "eval_counts: bad argument");
+    EvalArgs a{};
+    int nb = 0;
+    for (int s = 0; s < 3; ++s) {
+        YH_REQUIRE(grid[s] >= 0 && (grid[s] == 0 || (pred[s] && target[s])), "eval_counts: scale %d missing", s);
+        a.pred[s] = pred[s]; a.tgt[s] = target[s]; a.grid[s] = grid[s];
+        a.cells[s] = (int64_t)B * grid[s] * grid[s] * 3;
+        a.blk_begin[s] = nb;
+        nb += (int)cdiv64(a.cells[s], 256);
+    }
+    a.blk_begin[3] = nb;
+    YH_REQUIRE(nb > 0, "eval_counts: no cells");
+    for (int k = 0; k < 18; ++k) a.anchors[k] = anchors[k];
+    a.nc = nc; a.img = decode_img_size; a.conf = conf_thr; a.iou = iou_thr;
+    a.counts = (unsigned long long *)counts;
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    YH_CHECK_LAUNCH("eval_counts");
     return 0;
 }

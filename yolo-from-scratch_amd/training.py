@@ -15,9 +15,8 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from .functional import _OBJ_W, _W_BOX, _W_CLS, _anchors18, run_loss_kernel, yolo_loss_multiscale
-from .functional import decode_predictions
-from .hostside import compute_box_iou, stack_targets
+from .functional import LOSS_IMG_SIZE, _anchors18, run_loss_kernel, yolo_loss_multiscale
+from .hostside import stack_targets
 from .modules import HipModule
 
 
@@ -223,32 +222,26 @@ def train_epoch(model, loader, optimizer, device, num_classes=1):
 
 def eval_epoch(model, loader, device, num_classes=1, iou_threshold=0.5, conf_threshold=0.5):
     """Validation loss + same-cell/same-anchor precision, recall, F1 in percent (train.py:960-1032).
-    The reference walks every cell in Python; here the identical counting rule is evaluated with
-    tensor masks on the device."""
+    The reference walks every cell in Python with two `.item()` per cell; here one HIP kernel per batch
+    (yh_eval_counts) applies the identical counting rule and the three counters are read once per epoch."""
     model.eval()
     anchors_list = model.anchors
-    total_loss, tp, fp, fn, nb = 0.0, 0, 0, 0, 0
+    a18 = _anchors18(anchors_list)
+    counts = torch.zeros(3, device=device, dtype=torch.int64)
+    loss_acc = torch.zeros((), device=device, dtype=torch.float64)
+    nb = 0
     with torch.no_grad():
         for imgs, targets in loader:
             imgs = imgs.to(device)
-            tb = stack_targets(targets, device)
-            preds = model(imgs)
-            total_loss += yolo_loss_multiscale(preds, tb, anchors_list, num_classes)[0].item()
+            tb = [t.contiguous() for t in stack_targets(targets, device)]
+            preds = [p.contiguous() for p in model(imgs)]
+            loss_acc += yolo_loss_multiscale(preds, tb, anchors_list, num_classes)[0].double()
             nb += 1
-            for pred, tgt, anc in zip(preds, tb, anchors_list):
-                dec = decode_predictions(pred, anc)
-                pobj = torch.sigmoid(pred[..., 4]) > conf_threshold
-                tobj = tgt[..., 4] > conf_threshold
-                both = pobj & tobj
-                if bool(both.any()):
-                    pb, tbx = dec[..., 0:4][both], tgt[..., 0:4][both]
-                    iou = compute_box_iou(pb.t(), tbx.t())
-                    hit = int((iou > iou_threshold).sum())
-                    tp += hit
-                    fp += int(both.sum()) - hit
-                fp += int((pobj & ~tobj).sum())
-                fn += int((~pobj & tobj).sum())
+            L.check(L.lib().yh_eval_counts(L.ptr3(preds), L.ptr3(tb), L.floats(a18), L.int3([p.shape[1] for p in preds]),
+                                           preds[0].shape[0], num_classes, LOSS_IMG_SIZE, float(conf_threshold),
+                                           float(iou_threshold), counts.data_ptr(), _stream(device)), "eval_counts")
+    tp, fp, fn = (int(v) for v in counts.tolist())
     prec = tp / (tp + fp) if tp + fp > 0 else 0
     rec = tp / (tp + fn) if tp + fn > 0 else 0
     f1 = 2 * prec * rec / (prec + rec) if prec + rec > 0 else 0
-    return total_loss / max(nb, 1), prec * 100, rec * 100, f1 * 100
+    return float(loss_acc) / max(nb, 1), prec * 100, rec * 100, f1 * 100
