@@ -168,6 +168,14 @@ int yh_nms(const float *boxes, const float *scores, const int32_t *classes, cons
            float iou_thr, int32_t *keep, int32_t *nkeep, void *ws, void *stream);
 int64_t yh_nms_ws(int cap);
 
+/* ---- input side: label lists -> dense target grids --------------------------------- */
+/* labels: DEVICE double [B][maxn][5] = (class, xc, yc, w, h) normalised to the padded square image, nlabels:
+ * DEVICE int32 [B].  Writes the three (B,G,G,3,5+nc) fp32 target tensors (zeroed first) with the reference's rule:
+ * best shape-IoU anchor over all nine, cell = min(int(c*G), G-1), first label wins a cell/anchor, one-hot class.
+ * replaces: the target construction in YOLODataset.__getitem__ (train.py:140-205). */
+int yh_assign_targets(const double *labels, const int32_t *nlabels, int B, int maxn, const float *anchors,
+                      const int grid[3], int nc, int img_size, float *const target[3], void *stream);
+
 /* ---- optimiser: global-norm clip + Adam over flat buffers -------------------------------------- */
 /* norm_out[0] = grad_scale * ||g||_2 (fp32), deterministic two-stage fp64 reduce; ws >= yh_sqnorm_ws(n)
  * doubles.  grad_scale = 1/world_size folds the data-parallel mean into the norm.

@@ -182,3 +182,31 @@ def test_eval_epoch_counts_match_reference_loop(tag):
         want = g[f"{tag}/c{conf}_i{iou}"]
         np.testing.assert_allclose(got[0], want[0], rtol=1e-4)
         np.testing.assert_allclose(got[1:], want[1:], rtol=1e-9, atol=1e-12)     # integer counts -> identical ratios
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_device_target_assignment_matches_reference_dataset(nc):
+    """yh_assign_targets against what the reference's YOLODataset.__getitem__ produced for the same
+    label files (tests/golden/assign.npz) -- bit-exact cells, anchors and stored values -- and against the host rule."""
+    from conftest import load_golden
+    y = api()
+    g = load_golden("assign")
+    labels = [[(int(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4])) for r in img] for img in g[f"nc{nc}/labels"]]
+    tg = y.assign_targets_gpu(labels, 640, nc, torch.device("cuda"))
+    for b in range(3):
+        for s in range(3):
+            t = tg[s][b].cpu()
+            pos = t[..., 4] > 0.5
+            np.testing.assert_array_equal(pos.nonzero().numpy(), g[f"nc{nc}/b{b}/s{s}/idx"])
+            np.testing.assert_array_equal(t[pos].numpy(), g[f"nc{nc}/b{b}/s{s}/val"])
+    host = y.synthetic_targets(4, nc, 320, 12, 5)
+    rng = np.random.default_rng(5)
+    import math
+    lab = []
+    for _ in range(4):
+        c = rng.uniform(0.05, 0.95, size=(12, 2)); wh = np.exp(rng.uniform(math.log(8), math.log(320), size=(12, 2))) / 320
+        k = rng.integers(0, max(nc, 1), size=12)
+        lab.append([(int(k[i]), float(c[i, 0]), float(c[i, 1]), float(wh[i, 0]), float(wh[i, 1])) for i in range(12)])
+    dev = y.assign_targets_gpu(lab, 320, nc, torch.device("cuda"))
+    for a, b_ in zip(dev, host):
+        assert torch.equal(a.cpu(), b_)

@@ -251,6 +251,59 @@ __global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) 
     if (t == 0) a.nkeep[0] = nk_sh;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Target assignment of YOLODataset.__getitem__ (train.py:164-205) on the device: one thread per image walks
+// its labels IN ORDER (first writer wins), so the result is identical to the sequential host rule.
+// The reference mixes python floats (double) and float32 tensors; the same types are used here:
+// cell index and stored box from doubles, shape-IoU against the anchors in float32, no FMA contraction.
+struct AssignArgs {
+    const double *labels;     // [B][maxn][5] = class, xc, yc, w, h (normalised to the padded square image)
+    const int32_t *nlabels;   // [B]
+    float *tgt[3];
+    float anchors[18];
+    int grid[3];
+    int B, maxn, nc;
+    double img;
+};
+
+__global__ void assign_targets_kernel(const AssignArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int ch = 5 + a.nc;
+    const int n = a.nlabels[b] < a.maxn ? a.nlabels[b] : a.maxn;
+    for (int k = 0; k < n; ++k) {
+        const double *lab = a.labels + ((size_t)b * a.maxn + k) * 5;
+        const int cid = (int)lab[0];
+        const double xc = lab[1], yc = lab[2], w = lab[3], h = lab[4];
+        const float bw = (float)(w * a.img), bh = (float)(h * a.img);
+        float best = -1.f;
+        int bs = 0, ba = 0;
+        for (int s = 0; s < 3; ++s) {
+            float smax = -1.f;
+            int sarg = 0;
+            for (int an = 0; an < 3; ++an) {
+                float aw = a.anchors[(s * 3 + an) * 2], ah = a.anchors[(s * 3 + an) * 2 + 1];
+                float inter = fminf(bw, aw) * fminf(bh, ah);
+                float uni = (bw * bh + aw * ah) - inter;
+                float iou = inter / (uni + 1e-16f);
+                if (iou > smax) { smax = iou; sarg = an; }
+            }
+            if (smax > best) { best = smax; bs = s; ba = sarg; }
+        }
+        const int G = a.grid[bs];
+        int gx = (int)(xc * (double)G), gy = (int)(yc * (double)G);
+        gx = gx < G - 1 ? gx : G - 1;
+        gy = gy < G - 1 ? gy : G - 1;
+        if (gx < 0 || gy < 0) continue;
+        float *t = a.tgt[bs] + ((((size_t)b * G + gy) * G + gx) * 3 + ba) * ch;
+        if (t[4] == 0.f) {
+            t[0] = (float)xc; t[1] = (float)yc; t[2] = (float)w; t[3] = (float)h;
+            t[4] = 1.f;
+            t[a.nc == 1 ? 5 : 5 + cid] = 1.f;
+        }
+    }
+}
+
 inline int pow2_ge(int v) { int n = 1; while (n < v) n <<= 1; return n; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -331,5 +384,22 @@ extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *cl
     YH_CHECK_LAUNCH("nms_mask");
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kNmsThreads), 0, st, a);
     YH_CHECK_LAUNCH("nms_scan");
+    return 0;
+}
+
+extern "C" int yh_assign_targets(const double *labels, const int32_t *nlabels, int B, int maxn, const float *anchors,
+                                 const int grid[3], int nc, int img_size, float *const target[3], void *stream) {
+    YH_REQUIRE(labels && nlabels && anchors && grid && target && B > 0 && maxn > 0 && nc >= 1, "assign_targets: bad argument");
+    AssignArgs a{};
+    a.labels = labels; a.nlabels = nlabels; a.B = B; a.maxn = maxn; a.nc = nc; a.img = (double)img_size;
+    for (int k = 0; k < 18; ++k) a.anchors[k] = anchors[k];
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < 3; ++s) {
+        YH_REQUIRE(target[s] && grid[s] > 0, "assign_targets: scale %d missing", s);
+        a.tgt[s] = target[s]; a.grid[s] = grid[s];
+        YH_HIP(hipMemsetAsync(target[s], 0, (size_t)B * grid[s] * grid[s] * 3 * (5 + nc) * sizeof(float), st));
+    }
+    hipLaunchKernelGGL(assign_targets_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, a);
+    YH_CHECK_LAUNCH("assign_targets");
     return 0;
 }

@@ -153,3 +153,26 @@ class InferenceSession:
         else:
             self._enqueue()
         return self.det.fetch() if fetch else None
+
+
+def assign_targets_gpu(labels, img_size, num_classes, device, anchors=None):
+    """labels[b] = [(class, xc, yc, w, h), ...] normalised to the padded square image -> the three dense
+    (B,G,G,3,5+nc) target tensors, built on the device by yh_assign_targets (the rule of
+    YOLODataset.__getitem__, train.py:164-205)."""
+    from .modules import DEFAULT_ANCHORS
+    L.lib()
+    B = len(labels)
+    maxn = max(1, max((len(l) for l in labels), default=1))
+    lab = torch.zeros(B, maxn, 5, dtype=torch.float64)
+    cnt = torch.zeros(B, dtype=torch.int32)
+    for b, l in enumerate(labels):
+        cnt[b] = len(l)
+        if l:
+            lab[b, :len(l)] = torch.tensor([[float(v) for v in row] for row in l], dtype=torch.float64)
+    lab, cnt = lab.to(device), cnt.to(device)
+    grids = [img_size // 8, img_size // 16, img_size // 32]
+    out = [torch.empty(B, g, g, 3, 5 + num_classes, device=device, dtype=torch.float32) for g in grids]
+    a18 = [float(v) for sc in (anchors or DEFAULT_ANCHORS) for pair in sc for v in pair]
+    L.check(L.lib().yh_assign_targets(lab.data_ptr(), cnt.data_ptr(), B, maxn, L.floats(a18), L.int3(grids), num_classes,
+                                      int(img_size), L.ptr3(out), _stream(device)), "assign_targets")
+    return out
