@@ -88,3 +88,27 @@ def test_synthetic_targets_follow_the_reference_assignment_rule():
         want = orc.assign_targets(boxes, 320, nc)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+
+
+def test_checkpoint_round_trip_and_reference_style_grid_buffers(tmp_path):
+    """the reference's checkpoint dict round-trips, including a file whose grid_* buffers are
+    the reference's stride-0 expanded views (quirk Q5)."""
+    import yolo_from_scratch_amd as y
+    torch.manual_seed(2)
+    m = y.YOLO(num_classes=3, img_size=320, width_mult=0.25, depth_mult=0.33)
+    p = tmp_path / "yolo.pt"
+    y.save_checkpoint(m, 7, p)
+    ck = torch.load(p, weights_only=False)
+    assert set(ck) == {"model", "epoch", "num_classes", "img_size", "width_mult", "depth_mult"} and ck["epoch"] == 7
+    m2, ep = y.load_checkpoint(p)
+    assert ep == 7 and m2.num_classes == 3 and m2.img_size == 320
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    sd = dict(ck["model"])
+    g = 320 // 8
+    gy, gx = torch.meshgrid(torch.arange(g, dtype=torch.float32), torch.arange(g, dtype=torch.float32), indexing="ij")
+    sd["grid_x_p3"] = torch.arange(g, dtype=torch.float32).view(1, 1, g, 1).expand(1, g, g, 1)     # stride-0 view
+    assert not sd["grid_x_p3"].is_contiguous()
+    torch.save({**ck, "model": sd}, p)
+    m3, _ = y.load_checkpoint(p)
+    assert torch.equal(m3.grid_x_p3, gx.view(1, g, g, 1))

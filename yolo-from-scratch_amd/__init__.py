@@ -10,12 +10,13 @@ from .functional import ciou_loss, decode_predictions, yolo_loss, yolo_loss_mult
 from .inference import predict, batched_nms, Detector, InferenceSession, assign_targets_gpu
 from .training import train_epoch, eval_epoch, HipAdam, HipTrainer
 from .hostside import (nms, compute_iou_corners, compute_box_iou, get_lr_lambda, letterbox_resize, YOLODataset,
-                       yolo_collate_fn, compute_optimal_anchors, YOLO_SIZES, stack_targets, synthetic_targets)
+                       yolo_collate_fn, compute_optimal_anchors, YOLO_SIZES, stack_targets, synthetic_targets,
+                       save_checkpoint, load_checkpoint)
 
 __all__ = [
     "YOLO", "ConvBlock", "C3", "Bottleneck", "SPPF", "ciou_loss", "decode_predictions", "yolo_loss",
     "yolo_loss_multiscale", "predict", "batched_nms", "Detector", "InferenceSession", "assign_targets_gpu", "train_epoch", "eval_epoch", "HipAdam",
     "HipTrainer", "nms", "compute_iou_corners", "compute_box_iou", "get_lr_lambda", "letterbox_resize",
     "YOLODataset", "yolo_collate_fn", "compute_optimal_anchors", "YOLO_SIZES", "stack_targets", "load_library",
-    "LIB_PATH", "DEFAULT_ANCHORS", "synthetic_targets",
+    "LIB_PATH", "DEFAULT_ANCHORS", "synthetic_targets", "save_checkpoint", "load_checkpoint",
 ]

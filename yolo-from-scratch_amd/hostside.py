@@ -209,3 +209,25 @@ def synthetic_targets(batch, num_classes, img_size, n_obj=8, seed=2000, anchors=
                 t[gy, gx, ba, 4] = 1.0
                 t[gy, gx, ba, 5 if num_classes == 1 else 5 + int(cls[o])] = 1.0
     return out
+
+
+# ---- checkpoint format of the reference (train.py:1533-1540, load paths 1410-1417 / 1431-1438) -------------------
+def save_checkpoint(model, epoch, path):
+    """The reference's per-epoch dict: {'model': state_dict, 'epoch', 'num_classes', 'img_size', 'width_mult',
+    'depth_mult'}.  Tensors are saved on the CPU with OIHW weights, so the file loads in the reference too."""
+    torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "epoch": int(epoch),
+                "num_classes": model.num_classes, "img_size": model.img_size, "width_mult": model.width_mult,
+                "depth_mult": model.depth_mult}, path)
+
+
+def load_checkpoint(path, num_classes=None, device="cpu"):
+    """Rebuild YOLO from a checkpoint's metadata and load its weights (the reference's inference/eval load
+    path).  Reference-written files carry stride-0 expanded grid_* buffers (which makes the
+    reference's own load_state_dict fail on torch 2.x): here they are copied into contiguous buffers."""
+    from .modules import YOLO
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    nc = num_classes if num_classes is not None else ckpt.get("num_classes", 1)
+    model = YOLO(num_classes=nc, img_size=ckpt.get("img_size", 640), width_mult=ckpt.get("width_mult", 0.50),
+                 depth_mult=ckpt.get("depth_mult", 0.33))
+    model.load_state_dict(ckpt["model"])
+    return model.to(device), ckpt.get("epoch", 0)
