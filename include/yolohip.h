@@ -67,6 +67,11 @@ int yh_pack_fold_multi(const void *table, int n_layers, void *stream);
  * gradient) reached from loss.backward() (train.py:913). */
 int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi,
                      int Wi, int Cin, int Cout, int k, int s, int accumulate, void *stream);
+/* Backward-data of TWO pointwise (1x1, stride 1) convolutions that share their input (C3's conv1 / conv2):
+ * dx (+)= dy1 * W1^T + dy2 * W2^T as one GEMM over K = cout1 + cout2 (dx written once, no read-modify-write).
+ * dy1 / dy2: (B,H,W,*) views with the same ld; wb: the two backward packs stacked, rows [0,cout1) then [cout1, cout1+cout2). */
+int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wb, int ldwb,
+                          float *dx, int lddx, int B, int H, int W, int Cin, int accumulate, void *stream);
 /* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction
  * through `ws` (ws_floats >= yh_conv_bwd_weight_ws(...)).  Writes OIHW (Cin_real input channels)
  * into dw.  replaces: aten::convolution_backward (weight gradient), train.py:913. */
@@ -208,6 +213,7 @@ enum {
     YH_OP_CONV_BWD_WEIGHT, YH_OP_COLSUM, YH_OP_BN_FINALIZE, YH_OP_BN_EVAL_COEF, YH_OP_BN_SILU_FWD,
     YH_OP_BN_SILU_BWD_REDUCE, YH_OP_BN_SILU_BWD_APPLY, YH_OP_MAXPOOL5_FWD, YH_OP_MAXPOOL5_BWD, YH_OP_MEMSET,
     YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI, YH_OP_PACK_FOLD_MULTI, YH_OP_CONV_FWD_FUSED,
+    YH_OP_CONV_BWD_DATA_PAIR,
     YH_OP_FORK,   /* side lane waits for everything issued on the caller's stream so far */
     YH_OP_JOIN    /* caller's stream waits for everything issued on the side lane so far */
 };

@@ -24,6 +24,8 @@ constexpr int LDA = BK + 4;
 
 struct GatherGemm {
     const float *in, *w, *bias;
+    const float *in2;     // optional second input (same geometry and ld): k >= ksplit reads in2 (pointwise K-concatenation)
+    int ksplit;
     float *out, *stats;
     int Hi, Wi, ldi, Cin;
     int ldw;
@@ -134,10 +136,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
                 int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
                 int dy = tapt[tap], dx = tapt[9 + tap];
                 int toff = (dy * g.Wi + dx) * g.ldi + ci;
+                const float *inb = (g.in2 && k >= g.ksplit) ? g.in2 - g.ksplit : g.in;   // two-source K (pointwise only)
 #pragma unroll
                 for (int i = 0; i < AROWS; ++i) {
                     bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
-                    ra[i] = ok ? *(const f32x4 *)(g.in + (roff[i] + toff)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    ra[i] = ok ? *(const f32x4 *)(inb + (roff[i] + toff)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             } else {
 #pragma unroll
@@ -153,10 +156,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
                     int tap = (int)__umulhi((unsigned)ke, g.cin_magic), ci = ke - tap * g.Cin;
                     int dy = tapt[tap], dx = tapt[9 + tap];
                     int toff = (dy * g.Wi + dx) * g.ldi + ci;
+                    const float *inb = (g.in2 && ke >= g.ksplit) ? g.in2 - g.ksplit : g.in;
 #pragma unroll
                     for (int i = 0; i < AROWS; ++i) {
                         bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
-                        if (ok) ra[i][e] = g.in[roff[i] + toff];
+                        if (ok) ra[i][e] = inb[roff[i] + toff];
                     }
                 }
             }
@@ -493,4 +497,27 @@ extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int 
         case 3: return launch_set<3>(gs, st);
         default: return launch_set<4>(gs, st);
     }
+}
+
+// Backward-data of two pointwise (1x1, stride 1) convolutions that read the SAME input x (the conv1 / conv2 pair
+// of a C3 block): dx (+)= dy1 * W1^T + dy2 * W2^T as ONE GEMM with K = Cout1 + Cout2, so dx is written once
+// instead of written and then read-modified-written.  wb holds the two backward packs stacked: rows [0, Cout1)
+// from conv1, [Cout1, Cout1+Cout2) from conv2.
+extern "C" int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wb,
+                                     int ldwb, float *dx, int lddx, int B, int H, int W, int Cin, int accumulate,
+                                     void *stream) {
+    YH_REQUIRE(dy1 && dy2 && wb && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && cout1 > 0 && cout2 > 0,
+               "conv_bwd_data_pair: bad argument");
+    YH_REQUIRE(lddy >= cout1 && lddy >= cout2 && lddx >= Cin, "conv_bwd_data_pair: ld smaller than channel count");
+    YH_REQUIRE(cout1 % 4 == 0 && lddy % 4 == 0 && (((uintptr_t)dy1 | (uintptr_t)dy2) & 15) == 0,
+               "conv_bwd_data_pair: sources must be 16-byte addressable and Cout1 a multiple of 4");
+    GatherGemm g{};
+    g.in = dy1; g.in2 = dy2; g.ksplit = cout1; g.w = wb; g.bias = nullptr; g.out = dx; g.stats = nullptr;
+    g.Hi = H; g.Wi = W; g.ldi = lddy; g.Cin = cout1 + cout2; g.ldw = ldwb;
+    g.Ho_f = H; g.Wo_f = W; g.ldo = lddx; g.N = Cin;
+    g.B = B; g.Yo = H; g.Xo = W; g.M = B * H * W;
+    g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = 1;
+    g.nTaps = 1; g.Ktot = cout1 + cout2; g.accumulate = accumulate; g.dense = 1;
+    g.tap_dy[0] = 0; g.tap_dx[0] = 0; g.tap_w[0] = 0;
+    return launch(g, (hipStream_t)stream);
 }

@@ -95,6 +95,8 @@ class ConvRec:
     ldwb: int = 0
     need_dx: bool = True
     lane: int = 0
+    pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
+    pair_first: bool = False
 
 
 @dataclass
@@ -209,6 +211,16 @@ class Plan:
         keep: List[torch.Tensor] = []          # tensors referenced only through raw pointers
         packs: List[tuple] = []                # one descriptor per conv for the single pack launch
         folds: List[tuple] = []                # inference: BN folded into the packed weights
+        if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
+            # sibling pointwise convs (C3 conv1 / conv2) share one backward-data GEMM: K = Cout1 + Cout2
+            groups: Dict[tuple, List[ConvRec]] = {}
+            for r in self.recs:
+                if isinstance(r, ConvRec) and r.k == 1 and r.s == 1 and r.bn is not None and r.cout % 4 == 0:
+                    groups.setdefault((id(r.x.buf), r.x.off, r.x.C), []).append(r)
+            for grp in groups.values():
+                if len(grp) == 2 and grp[0].cout == grp[1].cout and (self.need_input_grad or grp[0].x.buf is not self.input):
+                    grp[0].pair, grp[1].pair = grp[1], grp[0]
+                    grp[0].pair_first = True
         for r in self.recs:
             if isinstance(r, SyncRec):
                 fwd.append(_op(L.OP_FORK if r.kind == "fork" else L.OP_JOIN))
@@ -234,7 +246,13 @@ class Plan:
                                       r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], lane=ln))
                     continue
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
-                r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
+                if r.pair is not None and r.need_dx:
+                    if r.pair_first:      # stacked backward packs: rows [0, c1) this conv, [c1, c1 + c2) its sibling
+                        stacked = torch.empty((r.cout + r.pair.cout) * r.ldwb, **f32)
+                        r.wb, r.pair.wb = stacked[: r.cout * r.ldwb], stacked[r.cout * r.ldwb:]
+                        keep.append(stacked)
+                else:
+                    r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
                 packs.append((r.weight.data_ptr(), r.wf.data_ptr(), r.wb.data_ptr() if r.wb is not None else 0,
                               r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
                 r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32) if r.bn is not None else None
@@ -313,6 +331,7 @@ class Plan:
                     ws_floats = max(ws_floats, lib.yh_colsum_ws(r.x.B * r.Ho * r.Wo, r.cout))
         self.ws = torch.empty(int(ws_floats), device=self.device, dtype=torch.float32)
         ops: List[L.YhOp] = []
+        pair_pending = set()
         self.grad_ready: Dict[int, int] = {}     # id(param) -> number of backward ops after which its grad is final
         for r in reversed(self.recs):
             if isinstance(r, SyncRec):
@@ -348,7 +367,15 @@ class Plan:
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
                            l=[self.ws.numel()]))
             self.grad_ready[id(r.weight)] = len(ops)
-            if r.need_dx:
+            if r.need_dx and r.pair is not None:
+                if id(r.pair) in pair_pending:      # second of the pair (in backward order): both dY are final now
+                    first, second = (r, r.pair) if r.pair_first else (r.pair, r)
+                    dst, acc = self._grad_target(r.x)
+                    ops.append(_op(L.OP_CONV_BWD_DATA_PAIR, p=[first.y, second.y, first.wb, dst],
+                                   i=[first.cout, second.cout, first.cout, first.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
+                else:
+                    pair_pending.add(id(r))
+            elif r.need_dx:
                 dst, acc = self._grad_target(r.x)
                 ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
                                i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
