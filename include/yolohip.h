@@ -72,6 +72,18 @@ int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float
  * dy1 / dy2: (B,H,W,*) views with the same ld; wb: the two backward packs stacked, rows [0,cout1) then [cout1, cout1+cout2). */
 int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wb, int ldwb,
                           float *dx, int lddx, int B, int H, int W, int Cin, int accumulate, void *stream);
+/* Winograd F(2x2,3x3) path for 3x3 / stride-1 / pad-1 convolutions with even H, W and K % 16 == 0 (K = Cin forward,
+ * Cout backward): the same results as yh_conv_fwd / yh_conv_bwd_data to fp32 rounding with 4/9 of the multiplies.
+ * yh_wino_weights transforms OIHW weights into U[16][K][ldu] (backward = 0: K = Cin, N = Cout; backward = 1: the
+ * flipped, transposed filter, K = Cout, N = Cin); ldu % 4 == 0, ldu >= N.  bn_partials: [yh_conv_wino_blocks][2][Cout]
+ * per-workgroup channel sums / sums of squares (same contract as yh_conv_fwd), or NULL.
+ * replaces: nn.Conv2d(k=3, s=1) forward and input gradient (train.py:260-265, 300-306, 913). */
+int yh_wino_weights(const float *oihw, float *U, int Cout, int Cin, int ldu, int backward, void *stream);
+int yh_conv_wino_blocks(int B, int H, int W);
+int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const float *bias, float *y, int ldy,
+                     float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
+int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
+                          int W, int Cin, int Cout, int accumulate, void *stream);
 /* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction
  * through `ws` (ws_floats >= yh_conv_bwd_weight_ws(...)).  Writes OIHW (Cin_real input channels)
  * into dw.  replaces: aten::convolution_backward (weight gradient), train.py:913. */

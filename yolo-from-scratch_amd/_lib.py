@@ -46,6 +46,10 @@ _SIGS = {
     "yh_pack_fold_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_wino_weights": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    "yh_conv_wino_blocks": (i32, [i32, i32, i32]),
+    "yh_conv_wino_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_wino_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_data_pair": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),

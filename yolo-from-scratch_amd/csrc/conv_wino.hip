@@ -1,0 +1,300 @@
+// Winograd F(2x2, 3x3) convolution on v_mfma_f32_32x32x2_f32 (gfx950), NHWC fp32, stride 1, pad 1.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, 4x4 input tile d, 3x3 filter g
+//
+// With channels the element-wise product becomes 16 independent GEMMs (one per position (xi, nu) of the 4x4
+// transformed tile):  M[p][tile][n] = sum_k V[p][tile][k] * U[p][k][n]  -- 4/9 of the multiplies of the direct
+// form (2.25x fewer MFMA cycles).  Everything is fused in one kernel, and the main loop touches neither LDS nor a
+// barrier:
+//   * a workgroup owns 32 consecutive output tiles (linear over batch x tile rows x tile cols) x 32*NT channels;
+//     wave w owns transform row xi = w (positions 4w .. 4w+3);
+//   * lane (tile = lane & 31, q = lane >> 5) loads, per chunk of 8 input channels, the two input rows that
+//     row xi of B^T d needs (4 pixels x float4 of channels 4q..4q+3 each), applies the transform in registers and
+//     holds V[nu][tile][4q..4q+3] -- which is exactly the A operand this lane feeds to the MFMA (row = lane & 31,
+//     k-group = lane >> 5), so V never leaves the register file;
+//   * U is pre-transformed into a k-quad interleaved layout [16][K/4][N][4], so a B fragment (4 k values of one
+//     column) is one float4 load, coalesced over the 32 columns of a tile; it is private to the wave as well;
+//   * loads for chunk c+1 are issued before the 32*NT/2 MFMAs of chunk c;
+//   * epilogue: the nu-contraction of A^T M A is lane-local (the four positions of a wave), the xi-contraction
+//     goes through LDS; then bias / accumulate / BatchNorm partial sums exactly as the direct kernel.
+// The same kernel computes backward-data (correlation of dY with the flipped, transposed filter).
+// Numerics: fp32 throughout; F(2,3) transform constants are {0, +-1, +-1/2}, error growth is a few ulp.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 8;           // input channels per chunk (2 k-quads: one per lane half)
+constexpr int TPB = 32;         // tiles per workgroup
+
+struct Wino {
+    const float *in, *U, *bias;
+    float *out, *stats;
+    int ldi, ldu, ldo;
+    int B, H, W, K, N;
+    int TW, TPI, ntiles;        // tile columns per row, tiles per image, total tiles
+    int accumulate;
+    unsigned tw_magic, tpi_magic;
+    int tw_shift, tpi_shift;
+};
+
+constexpr int ZPAD = 2048;      // padding pixels read zeros from here (K <= ZPAD)
+__device__ float wino_zeros[ZPAD + 8];
+
+__device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
+    return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void wino_kernel(const Wino g) {
+    constexpr int BNW = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tile0 = blockIdx.x * TPB, n0 = blockIdx.y * BNW;
+
+    // rows of the 4x4 input patch that transform row xi = wave combines: t = d[ra] + sg * d[rb]
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+
+    const float *dp[2][4];                     // per-lane pixel pointers; padding pixels point into wino_zeros
+    {
+        int tg = tile0 + lr;
+        bool tv = tg < g.ntiles;
+        if (!tv) tg = 0;
+        int b = fdiv(tg, g.tpi_magic, g.tpi_shift), r = tg - b * g.TPI;
+        int ty = fdiv(r, g.tw_magic, g.tw_shift), tx = r - ty * g.TW;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            int iy = 2 * ty - 1 + (rr ? rb : ra);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int ix = 2 * tx - 1 + c;
+                bool ok = tv && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                dp[rr][c] = (ok ? g.in + (size_t)((b * g.H + iy) * g.W + ix) * g.ldi : wino_zeros) + 4 * lh;
+            }
+        }
+    }
+    // U fragment addresses: ((pos*(K/4) + kq) * ldu + n) * 4, pos = 4*wave + nu, kq = chunk*2 + lh
+    const int kq4 = g.K >> 2;
+    const float *ub[NT];
+    bool uok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int n = n0 + j * 32 + lr;
+        uok[j] = n < g.ldu;
+        ub[j] = g.U + ((size_t)((4 * wave) * kq4 + lh) * g.ldu + (uok[j] ? n : 0)) * 4;
+    }
+    const size_t upos = (size_t)kq4 * g.ldu * 4;      // stride between positions
+    const size_t uchunk = (size_t)2 * g.ldu * 4;      // stride between chunks
+
+    // Two register sets (A, B), loop unrolled by two: the loads of one set are in flight behind the MFMAs of the
+    // other.  No branches, selects or LDS in the loop.
+    f32x4 dA[2][4], uA[4][NT], dB[2][4], uB[4][NT];
+    auto load_chunk = [&](int c, f32x4 (&d)[2][4], f32x4 (&u)[4][NT]) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) d[rr][cc] = *(const f32x4 *)(dp[rr][cc] + c * KC);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) u[v][j] = *(const f32x4 *)(ub[j] + v * upos + c * uchunk);
+    };
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
+
+    auto compute = [&](const f32x4 (&d)[2][4], const f32x4 (&u)[4][NT]) {
+        f32x4 tt[4], V[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) tt[cc] = d[0][cc] + sg * d[1][cc];
+        V[0] = tt[0] - tt[2];
+        V[1] = tt[1] + tt[2];
+        V[2] = tt[2] - tt[1];
+        V[3] = tt[1] - tt[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], u[v][j][e], acc[v][j], 0, 0, 0);
+    };
+    const int nchunks = g.K / KC;              // even (K % 16 == 0)
+    load_chunk(0, dA, uA);
+    for (int c = 0; c < nchunks; c += 2) {
+        load_chunk(c + 1, dB, uB);
+        __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the MFMAs they hide behind
+        compute(dA, uA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(c + 2 < nchunks ? c + 2 : c, dA, uA);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(dB, uB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- output transform.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
+    float *S = smem;                           // [xi 4][j 2][tile 32][ch BNW]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+            S[((wave * 2 + 0) * TPB + row) * BNW + j * 32 + lr] = m0 + m1 + m2;
+            S[((wave * 2 + 1) * TPB + row) * BNW + j * 32 + lr] = m1 - m2 - m3;
+        }
+    __syncthreads();
+    // xi-contraction + store: thread = (channel, tile group); 256 / BNW tile groups
+    constexpr int TG = 256 / BNW;
+    const int ch = t % BNW, tgp = t / BNW, n = n0 + ch;
+    const bool nok = n < g.N;
+    const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+    float csum = 0.f, csq = 0.f;
+    for (int it = 0; it < TPB / TG; ++it) {
+        const int tl = tgp + TG * it, tg = tile0 + tl;
+        if (tg >= g.ntiles) break;
+        int b = fdiv(tg, g.tpi_magic, g.tpi_shift), r = tg - b * g.TPI;
+        int ty = fdiv(r, g.tw_magic, g.tw_shift), tx = r - ty * g.TW;
+        if (!nok) continue;
+        float s[4][2];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[xi][j] = S[((xi * 2 + j) * TPB + tl) * BNW + ch];
+        float *o = g.out + ((size_t)(b * g.H + 2 * ty) * g.W + 2 * tx) * g.ldo + n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float y0 = s[0][j] + s[1][j] + s[2][j] + bias;
+            float y1 = s[1][j] - s[2][j] - s[3][j] + bias;
+            float *o0 = o + (size_t)j * g.ldo, *o1 = o0 + (size_t)g.W * g.ldo;
+            if (g.accumulate) { y0 += *o0; y1 += *o1; }
+            *o0 = y0; *o1 = y1;
+            csum += y0 + y1;
+            csq += y0 * y0 + y1 * y1;
+        }
+    }
+    if (g.stats) {
+        float *red = smem + 4 * 2 * TPB * BNW;   // [TG][BNW][2]
+        red[(tgp * BNW + ch) * 2 + 0] = csum;
+        red[(tgp * BNW + ch) * 2 + 1] = csq;
+        __syncthreads();
+        if (t < BNW && n0 + t < g.N) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < TG; ++w) { a0 += red[(w * BNW + t) * 2]; a1 += red[(w * BNW + t) * 2 + 1]; }
+            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = a0;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = a1;
+        }
+    }
+}
+
+// U[pos][k/4][n][k%4] = (G g G^T)[pos] with g = w[n][k][.][.] (forward, k = ci, n = co) or the flipped filter of
+// the transposed convolution, g[a][b] = w[k][n][2-a][2-b] (backward-data, k = co, n = ci).
+__global__ void wino_weights_kernel(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin, int ldu,
+                                    int bwd) {
+    const int K = bwd ? Cout : Cin, N = bwd ? Cin : Cout;
+    const int total = K * ldu;
+    const size_t pstride = (size_t)K * ldu;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int n = i % ldu, k = i / ldu;
+        float gg[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.f;
+                if (n < N) v = bwd ? w[((size_t)k * Cin + n) * 9 + (2 - a) * 3 + (2 - b)] : w[((size_t)n * Cin + k) * 9 + a * 3 + b];
+                gg[a][b] = v;
+            }
+        float t4[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t4[0][b] = gg[0][b];
+            t4[1][b] = 0.5f * (gg[0][b] + gg[1][b] + gg[2][b]);
+            t4[2][b] = 0.5f * (gg[0][b] - gg[1][b] + gg[2][b]);
+            t4[3][b] = gg[2][b];
+        }
+        const size_t base = ((size_t)(k >> 2) * ldu + n) * 4 + (k & 3);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float u0 = t4[a][0], u1 = 0.5f * (t4[a][0] + t4[a][1] + t4[a][2]), u2 = 0.5f * (t4[a][0] - t4[a][1] + t4[a][2]),
+                  u3 = t4[a][2];
+            U[base + (size_t)(a * 4 + 0) * pstride] = u0;
+            U[base + (size_t)(a * 4 + 1) * pstride] = u1;
+            U[base + (size_t)(a * 4 + 2) * pstride] = u2;
+            U[base + (size_t)(a * 4 + 3) * pstride] = u3;
+        }
+    }
+}
+
+void set_magic(unsigned d, unsigned &magic, int &shift) {
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    magic = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    shift = l - 1;
+}
+
+template <int NT>
+int launch_nt(const Wino &g, hipStream_t st) {
+    constexpr int BNW = 32 * NT;
+    constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        YH_HIP(hipFuncSetAttribute((const void *)wino_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL(wino_kernel<NT>, dim3(cdiv(g.ntiles, TPB), cdiv(g.N, BNW)), dim3(256), smem, st, g);
+    YH_CHECK_LAUNCH("wino");
+    return 0;
+}
+
+int launch_wino(Wino &g, hipStream_t st) {
+    YH_REQUIRE(g.H % 2 == 0 && g.W % 2 == 0, "conv_wino: H and W must be even");
+    YH_REQUIRE(g.K % (2 * KC) == 0 && g.K <= ZPAD && g.ldi % 4 == 0 && (((uintptr_t)g.in | (uintptr_t)g.U) & 15) == 0 && g.ldu >= g.N,
+               "conv_wino: K must be a multiple of 16 (<= 2048), buffers 16-byte addressable");
+    YH_REQUIRE((int64_t)g.B * g.H * g.W * g.ldi < (1ll << 31), "conv_wino: input exceeds 32-bit element offsets");
+    g.TW = g.W / 2; g.TPI = (g.H / 2) * g.TW; g.ntiles = g.B * g.TPI;
+    set_magic((unsigned)g.TW, g.tw_magic, g.tw_shift);
+    set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
+    return g.N <= 32 ? launch_nt<1>(g, st) : launch_nt<2>(g, st);
+}
+
+}  // namespace
+
+extern "C" int yh_conv_wino_blocks(int B, int H, int W) { return cdiv(B * (H / 2) * (W / 2), TPB); }
+
+extern "C" int yh_wino_weights(const float *oihw, float *U, int Cout, int Cin, int ldu, int backward, void *stream) {
+    YH_REQUIRE(oihw && U && Cout > 0 && Cin > 0 && ldu >= (backward ? Cin : Cout) && (backward ? Cout : Cin) % 4 == 0, "wino_weights: bad argument");
+    int total = (backward ? Cout : Cin) * ldu;
+    int blocks = cdiv(total, 256);
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, (hipStream_t)stream, oihw, U,
+                       Cout, Cin, ldu, backward);
+    YH_CHECK_LAUNCH("wino_weights");
+    return 0;
+}
+
+extern "C" int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const float *bias, float *y, int ldy,
+                                float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream) {
+    YH_REQUIRE(x && U && y && B > 0 && H > 0 && W > 0 && ldx >= Cin && ldy >= Cout, "conv_wino_fwd: bad argument");
+    Wino g{};
+    g.in = x; g.U = U; g.bias = bias; g.out = y; g.stats = bn_partials;
+    g.ldi = ldx; g.ldu = ldu; g.ldo = ldy; g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = Cout; g.accumulate = 0;
+    return launch_wino(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
+                                     int W, int Cin, int Cout, int accumulate, void *stream) {
+    YH_REQUIRE(dy && Ub && dx && B > 0 && H > 0 && W > 0 && lddy >= Cout && lddx >= Cin, "conv_wino_bwd_data: bad argument");
+    Wino g{};
+    g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
+    g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
+    return launch_wino(g, (hipStream_t)stream);
+}
