@@ -35,7 +35,8 @@ def plan_conv_flops(plan):
 
 
 def time_forward_convs(trainer, plan, imgs, targets, steps):
-    """HIP-event time of every OP_CONV_FWD launch (and, separately, of every op class) per step."""
+    """HIP-event time of every forward-convolution launch (direct gather-GEMM and Winograd kernels) and,
+    separately, of every op class, per step."""
     from yolo_from_scratch_amd import _lib as L
     import ctypes
     dev = trainer.device
@@ -57,7 +58,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind == L.OP_CONV_FWD:
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
@@ -171,6 +172,7 @@ def main():
     }
     if rank == 0 and not args.no_roofline:
         plan = model._plan_for(imgs)
+        from yolo_from_scratch_amd import _lib as L
         conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
         flops = plan_conv_flops(plan) * BATCH
         ach = flops / (conv_ms * 1e-3) / 1e12
@@ -181,7 +183,11 @@ def main():
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                               "traffic_note": "bytes per step over the same 62 launches (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.json); algorithmic 8.41e9",
-                              "kernel": "gather_gemm_kernel (forward convolutions)", "launches_per_step": n_launch,
+                              "kernel": "forward convolutions: gather_gemm_kernel (1x1, stride-2, stem) + wino_kernel (3x3 stride-1, "
+                                        "Winograd F(2x2,3x3): executes 4/9 of the algorithmic multiplies)",
+                              "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
+                              "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
+                              "launches_per_step": n_launch,
                               "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
         result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

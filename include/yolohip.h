@@ -79,6 +79,9 @@ int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cou
  * per-workgroup channel sums / sums of squares (same contract as yh_conv_fwd), or NULL.
  * replaces: nn.Conv2d(k=3, s=1) forward and input gradient (train.py:260-265, 300-306, 913). */
 int yh_wino_weights(const float *oihw, float *U, int Cout, int Cin, int ldu, int backward, void *stream);
+/* n transforms in one launch; `table` is a DEVICE array of 32-byte records { const float *oihw; float *U; int32 Cout, Cin,
+ * ldu, backward; }. */
+int yh_wino_weights_multi(const void *table, int n, void *stream);
 int yh_conv_wino_blocks(int B, int H, int W);
 int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const float *bias, float *y, int ldy,
                      float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
@@ -227,7 +230,8 @@ enum {
     YH_OP_ADD_INT64, YH_OP_PACK_WEIGHTS_MULTI, YH_OP_PACK_FOLD_MULTI, YH_OP_CONV_FWD_FUSED,
     YH_OP_CONV_BWD_DATA_PAIR,
     YH_OP_FORK,   /* side lane waits for everything issued on the caller's stream so far */
-    YH_OP_JOIN    /* caller's stream waits for everything issued on the side lane so far */
+    YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
+    YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side

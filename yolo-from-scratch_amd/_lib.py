@@ -27,7 +27,8 @@ class YhOp(C.Structure):
 (OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_PACK_WEIGHTS, OP_CONV_FWD, OP_CONV_BWD_DATA, OP_CONV_BWD_WEIGHT,
  OP_COLSUM, OP_BN_FINALIZE, OP_BN_EVAL_COEF, OP_BN_SILU_FWD, OP_BN_SILU_BWD_REDUCE, OP_BN_SILU_BWD_APPLY,
  OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI, OP_PACK_FOLD_MULTI,
- OP_CONV_FWD_FUSED, OP_CONV_BWD_DATA_PAIR, OP_FORK, OP_JOIN) = range(1, 23)
+ OP_CONV_FWD_FUSED, OP_CONV_BWD_DATA_PAIR, OP_FORK, OP_JOIN, OP_WINO_WEIGHTS_MULTI, OP_CONV_WINO_FWD,
+ OP_CONV_WINO_BWD_DATA) = range(1, 26)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -47,6 +48,7 @@ _SIGS = {
     "yh_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_wino_weights": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    "yh_wino_weights_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_wino_blocks": (i32, [i32, i32, i32]),
     "yh_conv_wino_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),

@@ -69,6 +69,14 @@ static int run_one(const yh_op &o, void *st) {
             return yh_memset(p[0], i[0], o.l[0], st);
         case YH_OP_ADD_INT64:
             return yh_add_int64((int64_t *)p[0], o.l[0], st);
+        case YH_OP_WINO_WEIGHTS_MULTI:
+            return yh_wino_weights_multi(p[0], i[0], st);
+        case YH_OP_CONV_WINO_FWD:
+            return yh_conv_wino_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3],
+                                    i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], st);
+        case YH_OP_CONV_WINO_BWD_DATA:
+            return yh_conv_wino_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
+                                         i[5], i[6], i[7], i[8], st);
         case YH_OP_CONV_BWD_DATA_PAIR:
             return yh_conv_bwd_data_pair((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
                                          (float *)p[3], i[4], i[5], i[6], i[7], i[8], i[9], st);

@@ -198,12 +198,20 @@ __global__ __launch_bounds__(256) void wino_kernel(const Wino g) {
 
 // U[pos][k/4][n][k%4] = (G g G^T)[pos] with g = w[n][k][.][.] (forward, k = ci, n = co) or the flipped filter of
 // the transposed convolution, g[a][b] = w[k][n][2-a][2-b] (backward-data, k = co, n = ci).
-__global__ void wino_weights_kernel(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin, int ldu,
-                                    int bwd) {
-    const int K = bwd ? Cout : Cin, N = bwd ? Cin : Cout;
+struct WinoWDesc {
+    const float *w;
+    float *U;
+    int Cout, Cin, ldu, bwd;
+};
+
+__device__ __forceinline__ void wino_weights_body(const WinoWDesc d, int first, int step) {
+    const float *__restrict__ w = d.w;
+    float *__restrict__ U = d.U;
+    const int Cin = d.Cin, ldu = d.ldu, bwd = d.bwd;
+    const int K = bwd ? d.Cout : Cin, N = bwd ? Cin : d.Cout;
     const int total = K * ldu;
     const size_t pstride = (size_t)K * ldu;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < total; i += step) {
         int n = i % ldu, k = i / ldu;
         float gg[3][3];
 #pragma unroll
@@ -233,6 +241,13 @@ __global__ void wino_weights_kernel(const float *__restrict__ w, float *__restri
             U[base + (size_t)(a * 4 + 3) * pstride] = u3;
         }
     }
+}
+
+__global__ void wino_weights_kernel(const WinoWDesc d) {
+    wino_weights_body(d, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+__global__ void wino_weights_multi_kernel(const WinoWDesc *__restrict__ tab) {
+    wino_weights_body(tab[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 void set_magic(unsigned d, unsigned &magic, int &shift) {
@@ -275,9 +290,17 @@ extern "C" int yh_wino_weights(const float *oihw, float *U, int Cout, int Cin, i
     YH_REQUIRE(oihw && U && Cout > 0 && Cin > 0 && ldu >= (backward ? Cin : Cout) && (backward ? Cout : Cin) % 4 == 0, "wino_weights: bad argument");
     int total = (backward ? Cout : Cin) * ldu;
     int blocks = cdiv(total, 256);
-    hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, (hipStream_t)stream, oihw, U,
-                       Cout, Cin, ldu, backward);
+    WinoWDesc d{oihw, U, Cout, Cin, ldu, backward};
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, (hipStream_t)stream, d);
     YH_CHECK_LAUNCH("wino_weights");
+    return 0;
+}
+
+extern "C" int yh_wino_weights_multi(const void *table, int n, void *stream) {
+    YH_REQUIRE(table && n > 0, "wino_weights_multi: bad argument");
+    static_assert(sizeof(WinoWDesc) == 32, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(wino_weights_multi_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const WinoWDesc *)table);
+    YH_CHECK_LAUNCH("wino_weights_multi");
     return 0;
 }
 

@@ -95,6 +95,8 @@ class ConvRec:
     ldwb: int = 0
     need_dx: bool = True
     lane: int = 0
+    wino_f: bool = False    # forward on the Winograd F(2x2,3x3) kernel
+    wino_b: bool = False    # backward-data on the Winograd kernel
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
 
@@ -211,6 +213,8 @@ class Plan:
         keep: List[torch.Tensor] = []          # tensors referenced only through raw pointers
         packs: List[tuple] = []                # one descriptor per conv for the single pack launch
         folds: List[tuple] = []                # inference: BN folded into the packed weights
+        winos: List[tuple] = []                # Winograd weight transforms (forward and backward-data)
+        use_wino = self.training and os.environ.get("YH_WINO", "1") != "0"
         if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
             # sibling pointwise convs (C3 conv1 / conv2) share one backward-data GEMM: K = Cout1 + Cout2
             groups: Dict[tuple, List[ConvRec]] = {}
@@ -246,27 +250,38 @@ class Plan:
                                       r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], lane=ln))
                     continue
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
+                wino_ok = use_wino and r.k == 3 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.x.ld % 4 == 0
+                r.wino_f = wino_ok and r.cin % 16 == 0 and r.cin <= 2048
+                r.wino_b = wino_ok and r.need_dx and r.cout % 16 == 0 and r.cout <= 2048
                 if r.pair is not None and r.need_dx:
                     if r.pair_first:      # stacked backward packs: rows [0, c1) this conv, [c1, c1 + c2) its sibling
                         stacked = torch.empty((r.cout + r.pair.cout) * r.ldwb, **f32)
                         r.wb, r.pair.wb = stacked[: r.cout * r.ldwb], stacked[r.cout * r.ldwb:]
                         keep.append(stacked)
                 else:
-                    r.wb = torch.empty(kk * r.cout * r.ldwb, **f32) if r.need_dx else None
-                packs.append((r.weight.data_ptr(), r.wf.data_ptr(), r.wb.data_ptr() if r.wb is not None else 0,
-                              r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
+                    r.wb = torch.empty((16 if r.wino_b else kk) * r.cout * r.ldwb, **f32) if r.need_dx else None
+                if r.wino_f:
+                    r.wf = torch.empty(16 * r.cin * r.ldwf, **f32)
+                    winos.append((r.weight.data_ptr(), r.wf.data_ptr(), r.cout, r.weight.shape[1], r.ldwf, 0))
+                if r.wino_b:
+                    winos.append((r.weight.data_ptr(), r.wb.data_ptr(), r.cout, r.weight.shape[1], r.ldwb, 1))
+                if not (r.wino_f and (r.wino_b or r.wb is None)):
+                    packs.append((r.weight.data_ptr(), 0 if r.wino_f else r.wf.data_ptr(),
+                                  r.wb.data_ptr() if (r.wb is not None and not r.wino_b) else 0,
+                                  r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
                 r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32) if r.bn is not None else None
                 if r.bn is not None:
                     r.coef = torch.empty(4 * r.cout, **f32)
                     ytarget, ldy = r.y, r.cout
                 else:
                     ytarget, ldy = None, r.out.ld
-                nblk = lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
+                nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
+                    lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                 M = r.x.B * r.Ho * r.Wo
                 if r.bn is not None:
                     nb_bwd = lib.yh_bn_bwd_blocks(M, r.cout)
                     r.part = torch.empty(max(nblk, nb_bwd) * 2 * r.cout, **f32)
-                fwd.append(_op(L.OP_CONV_FWD,
+                fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else L.OP_CONV_FWD,
                                p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                   r.part if r.bn is not None else None],
                                i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
@@ -291,6 +306,11 @@ class Plan:
             blob = b"".join(struct.pack("<QQQQQQQQiiiiif", *d) for d in folds)
             self.fold_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             fwd.insert(0, _op(L.OP_PACK_FOLD_MULTI, p=[self.fold_table], i=[len(folds)]))
+        if winos:
+            import struct
+            blob = b"".join(struct.pack("<QQiiii", *d) for d in winos)
+            self.wino_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            fwd.insert(0, _op(L.OP_WINO_WEIGHTS_MULTI, p=[self.wino_table], i=[len(winos)]))
         if packs:   # every conv's OIHW -> packed copies in ONE launch at the head of the forward list
             import struct
             blob = b"".join(struct.pack("<QQQiiiiiiii", *d, 0, 0) for d in packs)
@@ -377,8 +397,12 @@ class Plan:
                     pair_pending.add(id(r))
             elif r.need_dx:
                 dst, acc = self._grad_target(r.x)
-                ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
-                               i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
+                if r.wino_b:
+                    ops.append(_op(L.OP_CONV_WINO_BWD_DATA, p=[dy, r.wb, dst],
+                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, acc]))
+                else:
+                    ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
+                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
         return ops
 
     # ---- execution ----------------------------------------------------------------------------
