@@ -44,8 +44,8 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void wino_kernel(const Wino g) {
+template <int NT, int PIPE>
+__global__ __launch_bounds__(256, PIPE == 2 ? 1 : 2) void wino_kernel(const Wino g) {
     constexpr int BNW = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats)
 
@@ -128,16 +128,25 @@ __global__ __launch_bounds__(256) void wino_kernel(const Wino g) {
                     acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], u[v][j][e], acc[v][j], 0, 0, 0);
     };
     const int nchunks = g.K / KC;              // even (K % 16 == 0)
-    load_chunk(0, dA, uA);
-    for (int c = 0; c < nchunks; c += 2) {
-        load_chunk(c + 1, dB, uB);
-        __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the MFMAs they hide behind
-        compute(dA, uA);
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk(c + 2 < nchunks ? c + 2 : c, dA, uA);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(dB, uB);
-        __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PIPE == 2) {
+        load_chunk(0, dA, uA);
+        for (int c = 0; c < nchunks; c += 2) {
+            load_chunk(c + 1, dB, uB);
+            __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the MFMAs they hide behind
+            compute(dA, uA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(c + 2 < nchunks ? c + 2 : c, dA, uA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(dB, uB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {                                       // one register set, two waves per SIMD hide each other's loads
+        for (int c = 0; c < nchunks; ++c) {
+            load_chunk(c, dA, uA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(dA, uA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- output transform.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
@@ -257,16 +266,16 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
     shift = l - 1;
 }
 
-template <int NT>
+template <int NT, int PIPE>
 int launch_nt(const Wino &g, hipStream_t st) {
     constexpr int BNW = 32 * NT;
     constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        YH_HIP(hipFuncSetAttribute((const void *)wino_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        YH_HIP(hipFuncSetAttribute((const void *)wino_kernel<NT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
-    hipLaunchKernelGGL(wino_kernel<NT>, dim3(cdiv(g.ntiles, TPB), cdiv(g.N, BNW)), dim3(256), smem, st, g);
+    hipLaunchKernelGGL((wino_kernel<NT, PIPE>), dim3(cdiv(g.ntiles, TPB), cdiv(g.N, BNW)), dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("wino");
     return 0;
 }
@@ -279,7 +288,13 @@ int launch_wino(Wino &g, hipStream_t st) {
     g.TW = g.W / 2; g.TPI = (g.H / 2) * g.TW; g.ntiles = g.B * g.TPI;
     set_magic((unsigned)g.TW, g.tw_magic, g.tw_shift);
     set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
-    return g.N <= 32 ? launch_nt<1>(g, st) : launch_nt<2>(g, st);
+    // many workgroups: two resident per CU with one register set hide each other's prologue / epilogue (measured
+    // 1.1-1.25x on the 160^2 / 80^2 layers); few workgroups: the software-pipelined variant (1.1x on 20^2 layers)
+    static const int force = getenv("YH_WINO_PIPE") ? atoi(getenv("YH_WINO_PIPE")) : 0;
+    const int nblk = cdiv(g.ntiles, TPB) * cdiv(g.N, g.N <= 32 ? 32 : 64);
+    const int pipe = force ? force : (nblk >= 2048 ? 1 : 2);
+    if (g.N <= 32) return pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
+    return pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
 }
 
 }  // namespace
