@@ -68,7 +68,19 @@ def main():
                                                      Cin, Cout, 3, 1, 0, st))
         b_win = lambda: L.check(lib.yh_conv_wino_bwd_data(dy.data_ptr(), Cout, Ub.data_ptr(), ldub, dx1.data_ptr(), Cin, B, H,
                                                           W, Cin, Cout, 0, st))
+        nws0 = lib.yh_conv_bwd_weight_ws(B, H, W, Cin, Cout, 3, 1)
+        nws1 = lib.yh_conv_wino_bwd_weight_ws(B, H, W, Cin, Cout) if Cin % 32 == 0 and Cout % 32 == 0 else 0
+        ws = torch.empty(max(nws0, nws1, 1), device=dev)
+        dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
+        w_dir = lambda: L.check(lib.yh_conv_bwd_weight(x.data_ptr(), Cin, dy.data_ptr(), Cout, dw0.data_ptr(), ws.data_ptr(), nws0,
+                                                       B, H, W, Cin, Cin, Cout, 3, 1, st))
+        w_win = lambda: L.check(lib.yh_conv_wino_bwd_weight(x.data_ptr(), Cin, dy.data_ptr(), Cout, dw1.data_ptr(), ws.data_ptr(),
+                                                            nws1, B, H, W, Cin, Cout, st))
         t = [timed(f) for f in (f_dir, f_win, b_dir, b_win)]
+        tw = [timed(w_dir), timed(w_win) if nws1 else float("nan")]
+        wref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), w.shape, dy.permute(0, 3, 1, 2).double(), padding=1)
+        wsc = wref.abs().max().item()
+        ew = [(dw0 - wref).abs().max().item() / wsc, (dw1 - wref).abs().max().item() / wsc if nws1 else float("nan")]
         xr = x.permute(0, 3, 1, 2).double()
         ref = F.conv2d(xr, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
         dref = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
@@ -80,7 +92,7 @@ def main():
                  ((s1[1] - (y1.double() ** 2).sum((0, 1, 2))).abs().max() / (y1.double() ** 2).sum((0, 1, 2)).abs().max()).item())
         gf = 2.0 * B * H * W * Cin * Cout * 9 / 1e9
         print(f"{H}x{W} {Cin}->{Cout}: fwd direct {t[0]:.3f} ms ({gf / t[0]:.0f} TF) wino {t[1]:.3f} ms ({gf / t[1]:.0f} TF-eq) | "
-              f"dgrad direct {t[2]:.3f} wino {t[3]:.3f} | err fwd {e[0]:.1e}/{e[1]:.1e} dgrad {e[2]:.1e}/{e[3]:.1e} stats {es:.1e}",
+              f"dgrad direct {t[2]:.3f} wino {t[3]:.3f} | wgrad direct {tw[0]:.3f} wino {tw[1]:.3f} err {ew[0]:.1e}/{ew[1]:.1e} | err fwd {e[0]:.1e}/{e[1]:.1e} dgrad {e[2]:.1e}/{e[3]:.1e} stats {es:.1e}",
               flush=True)
 
 

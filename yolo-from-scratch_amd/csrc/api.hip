@@ -77,6 +77,9 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_WINO_BWD_DATA:
             return yh_conv_wino_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
                                          i[5], i[6], i[7], i[8], st);
+        case YH_OP_CONV_WINO_BWD_WEIGHT:
+            return yh_conv_wino_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
+                                           o.l[0], i[2], i[3], i[4], i[5], i[7], st);
         case YH_OP_CONV_BWD_DATA_PAIR:
             return yh_conv_bwd_data_pair((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
                                          (float *)p[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
@@ -145,7 +148,7 @@ extern "C" int yh_run(const yh_op *ops, int n, void *stream, int *failed) {
             }
             continue;
         }
-        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_COLSUM);
+        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT || kind == YH_OP_COLSUM);
         const bool side = (auto_side || ops[k].lane == 1) && side_ready();
         int rc;
         if (side) {

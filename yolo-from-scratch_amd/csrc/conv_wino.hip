@@ -45,7 +45,7 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 }
 
 template <int NT, int PIPE>
-__global__ __launch_bounds__(256, PIPE == 2 ? 1 : 2) void wino_kernel(const Wino g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ? 2 : 1, PIPE == 1 ? (NT == 1 ? 3 : 2) : 1))) void wino_kernel(const Wino g) {
     constexpr int BNW = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats)
 
@@ -139,6 +139,14 @@ __global__ __launch_bounds__(256, PIPE == 2 ? 1 : 2) void wino_kernel(const Wino
             __builtin_amdgcn_sched_barrier(0);
             compute(dB, uB);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (PIPE == 3) {               // same, scheduling left to the compiler
+        load_chunk(0, dA, uA);
+        for (int c = 0; c < nchunks; c += 2) {
+            load_chunk(c + 1, dB, uB);
+            compute(dA, uA);
+            load_chunk(c + 2 < nchunks ? c + 2 : c, dA, uA);
+            compute(dB, uB);
         }
     } else {                                       // one register set, two waves per SIMD hide each other's loads
         for (int c = 0; c < nchunks; ++c) {
@@ -259,6 +267,217 @@ __global__ void wino_weights_multi_kernel(const WinoWDesc *__restrict__ tab) {
     wino_weights_body(tab[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward-weight in the Winograd domain:  dU[p][ci][co] = sum_tiles V[p][tile][ci] * dM[p][tile][co],
+// dM = A dY A^T (4x4 from the 2x2 output-gradient tile), then dg = G^T dU G.  One MFMA k-step consumes a PAIR of
+// tiles: lane (c = lane & 31, h = lane >> 5) transforms tile 2s+h for input channel ci0 + c (A operand) and for
+// output channels co0 + NT*c + {0..NT-1} (B operands, a float / float2 load: column c of column-tile nt is channel
+// co0 + NT*c + nt) -- both operands are produced in the registers that feed the MFMA, no LDS in the loop.
+// Wave w owns transform row xi = w.  The tile range is split over blockIdx.x; every workgroup applies G^T . G to its
+// partial dU (nu lane-local, xi through LDS) and writes a [9][Cin][Cout] slab; a fixed-order reduction sums the
+// slabs (bitwise reproducible) into OIHW.
+struct WinoW {
+    const float *x, *dy;
+    float *ws;
+    int ldx, lddy;
+    int B, H, W, Cin, Cout;
+    int TW, TPI, ntiles, tps;   // tps: tiles per split (multiple of 8)
+    unsigned x_bytes, dy_bytes; // extent of the two views (buffer-load bounds)
+    unsigned tw_magic, tpi_magic;
+    int tw_shift, tpi_shift;
+};
+
+template <int NT>
+struct DyVec;
+template <>
+struct DyVec<1> { typedef float type; };
+template <>
+struct DyVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <int NT>
+__device__ __forceinline__ float dy_elem(const typename DyVec<NT>::type &v, int j);
+template <>
+__device__ __forceinline__ float dy_elem<1>(const float &v, int) { return v; }
+template <>
+__device__ __forceinline__ float dy_elem<2>(const DyVec<2>::type &v, int j) { return v[j]; }
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wgrad_kernel(const WinoW g) {
+    typedef typename DyVec<NT>::type dyv;
+    constexpr int SPS = 4;                     // k-steps (tile pairs) per pipeline stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: T[4][3][32][32*NT]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32 * NT;
+    const int t_begin = blockIdx.x * g.tps;
+    const int t_end = min(t_begin + g.tps, g.ntiles);
+
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+    const float ca = wave == 3 ? 0.f : 1.f;                    // row xi of A: (1,0) (1,1) (1,-1) (0,-1)
+    const float cb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+
+    // Buffer loads: out-of-range offsets return 0, so padding pixels and tiles past the range cost one select on a
+    // 32-bit offset (no pointer arithmetic, no branches).  The per-lane tile cursor (b, ty, tx) advances by two
+    // tiles per k-step.
+    // Buffer loads: out-of-range offsets return 0, so padding pixels and tiles past the range cost one OR on a
+    // 32-bit offset (bit 31 set = beyond num_records: views span < 2 GiB); no pointer arithmetic, no branches.
+    // The per-lane tile cursor (b, ty, tx) advances by two tiles per k-step.
+    // (Measured: moving the eight wave-uniform pixel displacements into the scalar-offset operand is 20% SLOWER.)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)g.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)g.dy, 0, g.dy_bytes, 0x00020000);
+    const unsigned xlane = (unsigned)(ci0 + lr) * 4u, dlane = (unsigned)(co0 + NT * lr) * 4u;
+    const int ldx4 = g.ldx * 4, ldd4 = g.lddy * 4, TH = g.H / 2;
+    int dxo[2][4];                             // wave-uniform byte offsets of the 2 x 4 input pixels from the tile origin
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) dxo[rr][cc] = ((((rr ? rb : ra) - 1) * g.W) + cc - 1) * ldx4;
+    int tg = t_begin + lh, cb_, cty, ctx;
+    {
+        int tgc = tg < g.ntiles ? tg : 0;
+        cb_ = fdiv(tgc, g.tpi_magic, g.tpi_shift);
+        int r = tgc - cb_ * g.TPI;
+        cty = fdiv(r, g.tw_magic, g.tw_shift);
+        ctx = r - cty * g.TW;
+    }
+
+    float XA[SPS][2][4], XB[SPS][2][4];
+    dyv DA[SPS][2][2], DB[SPS][2][2];
+    auto load_stage = [&](float (&X)[SPS][2][4], dyv (&D)[SPS][2][2]) {
+#pragma unroll
+        for (int q = 0; q < SPS; ++q) {
+            const bool tv = tg < t_end;
+            const int pix = __mul24(__mul24(cb_, g.H) + 2 * cty, g.W) + 2 * ctx;    // top-left OUTPUT pixel of the tile
+            const unsigned xo = (unsigned)__mul24(pix, ldx4) + xlane, dof = (unsigned)__mul24(pix, ldd4) + dlane;
+            const bool c0 = ctx > 0, c3 = ctx < g.TW - 1;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int iy = 2 * cty + (rr ? rb : ra) - 1;
+                const bool rok = tv & ((unsigned)iy < (unsigned)g.H);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const bool ok = rok & (cc == 0 ? c0 : (cc == 3 ? c3 : true));
+                    X[q][rr][cc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (xo + (unsigned)dxo[rr][cc]) | ((unsigned)!ok << 31), 0, 0));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned o = (dof + (unsigned)((i * g.W + j) * ldd4)) | ((unsigned)!tv << 31);
+                    if constexpr (NT == 1) D[q][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0));
+                    else D[q][i][j] = __builtin_bit_cast(dyv, __builtin_amdgcn_raw_buffer_load_b64(rd, o, 0, 0));
+                }
+            tg += 2;                           // branch-free cursor advance
+            ctx += 2;
+            const int wrap = ctx >= g.TW ? 1 : 0;
+            ctx -= wrap ? g.TW : 0;
+            cty += wrap;
+            const int wrap2 = cty >= TH ? 1 : 0;
+            cty = wrap2 ? 0 : cty;
+            cb_ += wrap2;
+        }
+    };
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
+
+    auto compute = [&](const float (&X)[SPS][2][4], const dyv (&D)[SPS][2][2]) {
+#pragma unroll
+        for (int q = 0; q < SPS; ++q) {
+            float tt[4], V[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) tt[cc] = X[q][0][cc] + sg * X[q][1][cc];
+            V[0] = tt[0] - tt[2];
+            V[1] = tt[1] + tt[2];
+            V[2] = tt[2] - tt[1];
+            V[3] = tt[1] - tt[3];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float r0 = ca * dy_elem<NT>(D[q][0][0], j) + cb * dy_elem<NT>(D[q][1][0], j);
+                float r1 = ca * dy_elem<NT>(D[q][0][1], j) + cb * dy_elem<NT>(D[q][1][1], j);
+                float dM[4] = {r0, r0 + r1, r0 - r1, -r1};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v], dM[v], acc[v][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // one wave per SIMD by design (amdgpu_waves_per_eu(1, 1)): the scheduler is free to use the whole register file
+    // and interleaves the next stage's loads and address arithmetic with the MFMAs of the current one
+    const int nstages = (g.tps / 2) / SPS;
+    load_stage(XA, DA);
+    int sidx = 0;
+    for (; sidx + 2 <= nstages; sidx += 2) {
+        load_stage(XB, DB);
+        compute(XA, DA);
+        load_stage(XA, DA);                    // past the range: every tile invalid -> zeros
+        compute(XB, DB);
+    }
+    if (sidx < nstages) compute(XA, DA);
+
+    // ---- dg = G^T dU G.  nu-contraction, lane-local: T[b] = sum_nu dU[xi][nu] G[nu][b] ---------------------------
+    constexpr int BNW = 32 * NT;
+    float *T = smem;                           // [xi 4][b 3][row 32][col BNW]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float a0 = acc[0][j][r], a1 = acc[1][j][r], a2 = acc[2][j][r], a3 = acc[3][j][r];
+            float h = 0.5f * (a1 + a2);
+            float *o = T + ((wave * 3) * 32 + row) * BNW + NT * lr + j;
+            o[0] = a0 + h;
+            o[32 * BNW] = 0.5f * (a1 - a2);
+            o[2 * 32 * BNW] = h + a3;
+        }
+    __syncthreads();
+    // xi-contraction + slab write: dg[a][b] = sum_xi G[xi][a] T[xi][b]
+    float *slab = g.ws + (size_t)blockIdx.x * 9 * g.Cin * g.Cout;
+    for (int e = t; e < 3 * 32 * BNW; e += 256) {
+        int col = e % BNW, q = e / BNW, row = q % 32, b = q / 32;
+        float T0 = T[((0 * 3 + b) * 32 + row) * BNW + col], T1 = T[((1 * 3 + b) * 32 + row) * BNW + col];
+        float T2 = T[((2 * 3 + b) * 32 + row) * BNW + col], T3 = T[((3 * 3 + b) * 32 + row) * BNW + col];
+        float h = 0.5f * (T1 + T2);
+        size_t o = (size_t)(ci0 + row) * g.Cout + co0 + col;
+        size_t tapstride = (size_t)g.Cin * g.Cout;
+        slab[(0 * 3 + b) * tapstride + o] = T0 + h;
+        slab[(1 * 3 + b) * tapstride + o] = 0.5f * (T1 - T2);
+        slab[(2 * 3 + b) * tapstride + o] = h + T3;
+    }
+}
+
+// ws [nsplit][9][Cin][Cout] -> dw OIHW: 16 split-lanes each add every 16th slab, lanes combined in order (the
+// summation order is fixed).
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int nsplit,
+                                                                int Cin, int Cout) {
+    __shared__ float red[16][17];
+    const int n = 9 * Cin * Cout;
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (i < n)
+        for (int k = sl; k < nsplit; k += 16) s += ws[(size_t)k * n + i];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][e];
+        int co = i % Cout, q = i / Cout;
+        int ci = q % Cin, tap = q / Cin;
+        dw[((size_t)co * Cin + ci) * 9 + tap] = tot;
+    }
+}
+
 void set_magic(unsigned d, unsigned &magic, int &shift) {
     int l = 0;
     while ((1u << l) < d) ++l;
@@ -293,11 +512,75 @@ int launch_wino(Wino &g, hipStream_t st) {
     static const int force = getenv("YH_WINO_PIPE") ? atoi(getenv("YH_WINO_PIPE")) : 0;
     const int nblk = cdiv(g.ntiles, TPB) * cdiv(g.N, g.N <= 32 ? 32 : 64);
     const int pipe = force ? force : (nblk >= 2048 ? 1 : 2);
-    if (g.N <= 32) return pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
-    return pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
+    if (g.N <= 32) return pipe == 2 ? launch_nt<1, 2>(g, st) : (pipe == 3 ? launch_nt<1, 3>(g, st) : launch_nt<1, 1>(g, st));
+    return pipe == 2 ? launch_nt<2, 2>(g, st) : (pipe == 3 ? launch_nt<2, 3>(g, st) : launch_nt<2, 1>(g, st));
 }
 
 }  // namespace
+
+namespace {
+int wgrad_plan(WinoW &g, int &nsplit, int &NT, int B, int H, int W, int Cin, int Cout) {
+    YH_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 32 == 0, "conv_wino_bwd_weight: even H, W and channels % 32 == 0");
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.TW = W / 2; g.TPI = (H / 2) * g.TW; g.ntiles = B * g.TPI;
+    set_magic((unsigned)g.TW, g.tw_magic, g.tw_shift);
+    set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
+    NT = Cout % 64 == 0 ? 2 : 1;
+    int pairs = (Cin / 32) * (Cout / (32 * NT));
+    static const int target = getenv("YH_WINO_WGRAD_BLOCKS") ? atoi(getenv("YH_WINO_WGRAD_BLOCKS")) : 512;
+    nsplit = target / pairs;
+    if (nsplit < 1) nsplit = 1;
+    int tps = cdiv(cdiv(g.ntiles, nsplit), 8) * 8;
+    if (tps < 64) tps = 64;
+    nsplit = cdiv(g.ntiles, tps);
+    g.tps = tps;
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t yh_conv_wino_bwd_weight_ws(int B, int H, int W, int Cin, int Cout) {
+    WinoW g{};
+    int nsplit, NT;
+    if (wgrad_plan(g, nsplit, NT, B, H, W, Cin, Cout)) return -1;
+    return (int64_t)nsplit * 9 * Cin * Cout;
+}
+
+extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                                       int B, int H, int W, int Cin, int Cout, void *stream) {
+    YH_REQUIRE(x && dy && dw && ws && ldx >= Cin && lddy >= Cout, "conv_wino_bwd_weight: bad argument");
+    WinoW g{};
+    int nsplit, NT;
+    int rc = wgrad_plan(g, nsplit, NT, B, H, W, Cin, Cout);
+    if (rc) return rc;
+    YH_REQUIRE(ws_floats >= (int64_t)nsplit * 9 * Cin * Cout, "conv_wino_bwd_weight: workspace too small");
+    YH_REQUIRE((int64_t)B * H * W * (ldx > lddy ? ldx : lddy) < (1ll << 31), "conv_wino_bwd_weight: tensor exceeds 32-bit element offsets");
+    YH_REQUIRE(NT == 1 || ((((uintptr_t)dy) & 7) == 0 && lddy % 2 == 0), "conv_wino_bwd_weight: dy must be 8-byte addressable");
+    g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy;
+    const int64_t npix = (int64_t)B * H * W;
+    YH_REQUIRE(((npix - 1) * ldx + Cin) * 4 < (1ll << 31) && ((npix - 1) * lddy + Cout) * 4 < (1ll << 31) && W >= 4,
+               "conv_wino_bwd_weight: views must span less than 2 GiB");
+    g.x_bytes = (unsigned)(((npix - 1) * ldx + Cin) * 4);
+    g.dy_bytes = (unsigned)(((npix - 1) * lddy + Cout) * 4);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nsplit, Cin / 32, Cout / (32 * NT));
+    if (NT == 2) {
+        constexpr size_t smem = (size_t)4 * 3 * 32 * 64 * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            YH_HIP(hipFuncSetAttribute((const void *)wino_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr = true;
+        }
+        hipLaunchKernelGGL(wino_wgrad_kernel<2>, grid, dim3(256), smem, st, g);
+    } else {
+        constexpr size_t smem = (size_t)4 * 3 * 32 * 32 * sizeof(float);
+        hipLaunchKernelGGL(wino_wgrad_kernel<1>, grid, dim3(256), smem, st, g);
+    }
+    YH_CHECK_LAUNCH("wino_wgrad");
+    int n = 9 * Cin * Cout;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, ws, dw, nsplit, Cin, Cout);
+    YH_CHECK_LAUNCH("wino_wgrad_reduce");
+    return 0;
+}
 
 extern "C" int yh_conv_wino_blocks(int B, int H, int W) { return cdiv(B * (H / 2) * (W / 2), TPB); }
 

@@ -97,6 +97,7 @@ class ConvRec:
     lane: int = 0
     wino_f: bool = False    # forward on the Winograd F(2x2,3x3) kernel
     wino_b: bool = False    # backward-data on the Winograd kernel
+    wino_w: bool = False    # backward-weight in the Winograd domain
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
 
@@ -253,6 +254,7 @@ class Plan:
                 wino_ok = use_wino and r.k == 3 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.x.ld % 4 == 0
                 r.wino_f = wino_ok and r.cin % 16 == 0 and r.cin <= 2048
                 r.wino_b = wino_ok and r.need_dx and r.cout % 16 == 0 and r.cout <= 2048
+                r.wino_w = wino_ok and r.cin % 32 == 0 and r.cout % 32 == 0 and r.x.W >= 4
                 if r.pair is not None and r.need_dx:
                     if r.pair_first:      # stacked backward packs: rows [0, c1) this conv, [c1, c1 + c2) its sibling
                         stacked = torch.empty((r.cout + r.pair.cout) * r.ldwb, **f32)
@@ -346,7 +348,8 @@ class Plan:
         ws_floats = 1
         for r in self.recs:
             if isinstance(r, ConvRec):
-                ws_floats = max(ws_floats, lib.yh_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
+                ws_floats = max(ws_floats, lib.yh_conv_wino_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout) if r.wino_w else
+                                lib.yh_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
                 if r.bias is not None:
                     ws_floats = max(ws_floats, lib.yh_colsum_ws(r.x.B * r.Ho * r.Wo, r.cout))
         self.ws = torch.empty(int(ws_floats), device=self.device, dtype=torch.float32)
@@ -383,7 +386,8 @@ class Plan:
             if r.bias is not None:
                 ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
-            ops.append(_op(L.OP_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+            ops.append(_op(L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else L.OP_CONV_BWD_WEIGHT,
+                           p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
                            l=[self.ws.numel()]))
             self.grad_ready[id(r.weight)] = len(ops)
