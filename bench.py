@@ -27,11 +27,13 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)
 
 def plan_conv_flops(plan):
     from yolo_from_scratch_amd.graph import ConvRec
-    fl = 0
+    fl = fw = 0
     for r in plan.recs:
         if isinstance(r, ConvRec):
-            fl += 2 * r.weight.shape[1] * r.cout * r.k * r.k * r.Ho * r.Wo
-    return fl   # per image
+            f = 2 * r.weight.shape[1] * r.cout * r.k * r.k * r.Ho * r.Wo
+            fl += f
+            fw += f if r.wino_f else 0
+    return fl, fw   # per image: all forward convs, and the part on the Winograd kernel
 
 
 def time_forward_convs(trainer, plan, imgs, targets, steps):
@@ -174,7 +176,7 @@ def main():
         plan = model._plan_for(imgs)
         from yolo_from_scratch_amd import _lib as L
         conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
-        flops = plan_conv_flops(plan) * BATCH
+        flops, flops_wino = (v * BATCH for v in plan_conv_flops(plan))
         ach = flops / (conv_ms * 1e-3) / 1e12
         traffic = None          # HBM bytes of the same 62 launches, from the committed rocprofv3 PMC passes
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
@@ -187,6 +189,7 @@ def main():
                                         "Winograd F(2x2,3x3): executes 4/9 of the algorithmic multiplies)",
                               "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
                               "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
+                              "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
                               "launches_per_step": n_launch,
                               "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
         result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items())}

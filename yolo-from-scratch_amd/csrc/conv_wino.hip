@@ -140,14 +140,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             compute(dB, uB);
             __builtin_amdgcn_sched_barrier(0);
         }
-    } else if constexpr (PIPE == 3) {               // same, scheduling left to the compiler
-        load_chunk(0, dA, uA);
-        for (int c = 0; c < nchunks; c += 2) {
-            load_chunk(c + 1, dB, uB);
-            compute(dA, uA);
-            load_chunk(c + 2 < nchunks ? c + 2 : c, dA, uA);
-            compute(dB, uB);
-        }
     } else {                                       // one register set, two waves per SIMD hide each other's loads
         for (int c = 0; c < nchunks; ++c) {
             load_chunk(c, dA, uA);
@@ -301,11 +293,11 @@ __device__ __forceinline__ float dy_elem<1>(const float &v, int) { return v; }
 template <>
 __device__ __forceinline__ float dy_elem<2>(const DyVec<2>::type &v, int j) { return v[j]; }
 
-template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wgrad_kernel(const WinoW g) {
+template <int NT, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void wino_wgrad_kernel(const WinoW g) {
     typedef typename DyVec<NT>::type dyv;
     constexpr int SPS = 4;                     // k-steps (tile pairs) per pipeline stage
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: T[4][3][32][32*NT]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: T[4][32][32*NT]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -424,34 +416,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (sidx < nstages) compute(XA, DA);
 
-    // ---- dg = G^T dU G.  nu-contraction, lane-local: T[b] = sum_nu dU[xi][nu] G[nu][b] ---------------------------
+    // ---- dg = G^T dU G.  nu-contraction lane-local: T[b] = sum_nu dU[xi][nu] G[nu][b]; xi-contraction through LDS,
+    // one filter column b per pass (32 KB of LDS instead of 96) --------------------------------------------------------
     constexpr int BNW = 32 * NT;
-    float *T = smem;                           // [xi 4][b 3][row 32][col BNW]
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float a0 = acc[0][j][r], a1 = acc[1][j][r], a2 = acc[2][j][r], a3 = acc[3][j][r];
-            float h = 0.5f * (a1 + a2);
-            float *o = T + ((wave * 3) * 32 + row) * BNW + NT * lr + j;
-            o[0] = a0 + h;
-            o[32 * BNW] = 0.5f * (a1 - a2);
-            o[2 * 32 * BNW] = h + a3;
-        }
-    __syncthreads();
-    // xi-contraction + slab write: dg[a][b] = sum_xi G[xi][a] T[xi][b]
+    float *T = smem;                           // [xi 4][row 32][col BNW]
     float *slab = g.ws + (size_t)blockIdx.x * 9 * g.Cin * g.Cout;
-    for (int e = t; e < 3 * 32 * BNW; e += 256) {
-        int col = e % BNW, q = e / BNW, row = q % 32, b = q / 32;
-        float T0 = T[((0 * 3 + b) * 32 + row) * BNW + col], T1 = T[((1 * 3 + b) * 32 + row) * BNW + col];
-        float T2 = T[((2 * 3 + b) * 32 + row) * BNW + col], T3 = T[((3 * 3 + b) * 32 + row) * BNW + col];
-        float h = 0.5f * (T1 + T2);
-        size_t o = (size_t)(ci0 + row) * g.Cout + co0 + col;
-        size_t tapstride = (size_t)g.Cin * g.Cout;
-        slab[(0 * 3 + b) * tapstride + o] = T0 + h;
-        slab[(1 * 3 + b) * tapstride + o] = 0.5f * (T1 - T2);
-        slab[(2 * 3 + b) * tapstride + o] = h + T3;
+    const size_t tapstride = (size_t)g.Cin * g.Cout;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float a0 = acc[0][j][r], a1 = acc[1][j][r], a2 = acc[2][j][r], a3 = acc[3][j][r];
+                float v = b == 0 ? a0 + 0.5f * (a1 + a2) : (b == 1 ? 0.5f * (a1 - a2) : 0.5f * (a1 + a2) + a3);
+                T[(wave * 32 + row) * BNW + NT * lr + j] = v;
+            }
+        __syncthreads();
+        for (int e = t; e < 32 * BNW; e += 256) {
+            int col = e % BNW, row = e / BNW;
+            float T0 = T[(0 * 32 + row) * BNW + col], T1 = T[(1 * 32 + row) * BNW + col];
+            float T2 = T[(2 * 32 + row) * BNW + col], T3 = T[(3 * 32 + row) * BNW + col];
+            float h = 0.5f * (T1 + T2);
+            size_t o = (size_t)(ci0 + row) * g.Cout + co0 + col;
+            slab[(0 * 3 + b) * tapstride + o] = T0 + h;
+            slab[(1 * 3 + b) * tapstride + o] = 0.5f * (T1 - T2);
+            slab[(2 * 3 + b) * tapstride + o] = h + T3;
+        }
     }
 }
 
@@ -508,12 +501,14 @@ int launch_wino(Wino &g, hipStream_t st) {
     set_magic((unsigned)g.TW, g.tw_magic, g.tw_shift);
     set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
     // many workgroups: two resident per CU with one register set hide each other's prologue / epilogue (measured
-    // 1.1-1.25x on the 160^2 / 80^2 layers); few workgroups: the software-pipelined variant (1.1x on 20^2 layers)
+    // 1.1-1.25x on the 160^2 / 80^2 layers); few workgroups: the software-pipelined variant (1.1x on 20^2 layers).
+    // Tried and dropped: prefetch distance 2 (three register sets: no change), compiler-scheduled or
+    // sched_group_barrier-interleaved loads among the MFMAs (15-25 % slower than loads pinned ahead of them).
     static const int force = getenv("YH_WINO_PIPE") ? atoi(getenv("YH_WINO_PIPE")) : 0;
     const int nblk = cdiv(g.ntiles, TPB) * cdiv(g.N, g.N <= 32 ? 32 : 64);
     const int pipe = force ? force : (nblk >= 2048 ? 1 : 2);
-    if (g.N <= 32) return pipe == 2 ? launch_nt<1, 2>(g, st) : (pipe == 3 ? launch_nt<1, 3>(g, st) : launch_nt<1, 1>(g, st));
-    return pipe == 2 ? launch_nt<2, 2>(g, st) : (pipe == 3 ? launch_nt<2, 3>(g, st) : launch_nt<2, 1>(g, st));
+    if (g.N <= 32) return pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
+    return pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
 }
 
 }  // namespace
@@ -563,18 +558,11 @@ extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy,
     g.dy_bytes = (unsigned)(((npix - 1) * lddy + Cout) * 4);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nsplit, Cin / 32, Cout / (32 * NT));
-    if (NT == 2) {
-        constexpr size_t smem = (size_t)4 * 3 * 32 * 64 * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            YH_HIP(hipFuncSetAttribute((const void *)wino_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr = true;
-        }
-        hipLaunchKernelGGL(wino_wgrad_kernel<2>, grid, dim3(256), smem, st, g);
-    } else {
-        constexpr size_t smem = (size_t)4 * 3 * 32 * 32 * sizeof(float);
-        hipLaunchKernelGGL(wino_wgrad_kernel<1>, grid, dim3(256), smem, st, g);
-    }
+    // two waves per SIMD hide each other's address arithmetic for the 64-column variant (0.222 -> 0.187 ms on 64->64 @80^2);
+    // the 32-column variant spills at that register budget and stays at one
+    const size_t smem = (size_t)4 * 32 * 32 * NT * sizeof(float);
+    if (NT == 2) hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), grid, dim3(256), smem, st, g);
+    else hipLaunchKernelGGL((wino_wgrad_kernel<1, 1>), grid, dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("wino_wgrad");
     int n = 9 * Cin * Cout;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, ws, dw, nsplit, Cin, Cout);
