@@ -60,7 +60,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD):
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
@@ -189,6 +189,7 @@ def main():
                                         "Winograd F(2x2,3x3): executes 4/9 of the algorithmic multiplies)",
                               "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
                               "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
+                              "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0), 3),
                               "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
                               "launches_per_step": n_launch,
                               "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}

@@ -93,6 +93,27 @@ int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, 
 int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
                             int B, int H, int W, int Cin, int Cout, void *stream);
 int64_t yh_conv_wino_bwd_weight_ws(int B, int H, int W, int Cin, int Cout);
+/* Backward-weight of a pointwise (1x1, stride 1) convolution over M = B*H*W pixels: dw[co][ci] = sum_p x[p][ci] dy[p][co],
+ * MFMA operands loaded straight into registers (no LDS in the loop), deterministic slab reduction through ws
+ * (ws_floats >= yh_conv_pw_bwd_weight_ws(...)).  Same result as yh_conv_bwd_weight with k = 1, s = 1.
+ * replaces: aten::convolution_backward (weight gradient) of every 1x1 conv, train.py:913. */
+int yh_conv_pw_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                          int64_t M, int Cin, int Cout, void *stream);
+int64_t yh_conv_pw_bwd_weight_ws(int64_t M, int Cin, int Cout);
+/* Forward / backward-data of a pointwise (1x1, stride 1) convolution over M = B*H*W pixels as a register-direct MFMA
+ * GEMM (no LDS in the loop).  Weights in the k-quad interleaved layout Wq[K/4][ldw][4] written by yh_pw_pack_multi
+ * (`table`: DEVICE array of 48-byte records { const float *oihw; float *wq_fwd, *wq_bwd; int32 Cout, Cin, ldw_fwd,
+ * ldw_bwd, koff_bwd, 0 }; either destination may be NULL; koff_bwd = first K row of this conv inside a stacked
+ * backward matrix).  Channel counts feeding K must be multiples of 8.  yh_conv_pw_fwd: same contract as yh_conv_fwd
+ * (k = 1), bn_partials [yh_conv_pw_blocks(M, Cout)][2][Cout].  yh_conv_pw_bwd_data: dx (+)= dy1 W1^T (+ dy2 W2^T when
+ * dy2 != NULL: the C3 sibling pair, K = cout1 + cout2 stacked in wq).
+ * replaces: nn.Conv2d(k=1) forward and input gradient, train.py:236-240, 282-296, 402-418, 913. */
+int yh_pw_pack_multi(const void *table, int n, void *stream);
+int yh_conv_pw_blocks(int64_t M, int Cout);
+int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const float *bias, float *y, int ldy, float *bn_partials,
+                   int64_t M, int Cin, int Cout, void *stream);
+int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw, float *dx,
+                        int lddx, int64_t M, int Cin, int accumulate, void *stream);
 /* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction
  * through `ws` (ws_floats >= yh_conv_bwd_weight_ws(...)).  Writes OIHW (Cin_real input channels)
  * into dw.  replaces: aten::convolution_backward (weight gradient), train.py:913. */
@@ -237,7 +258,8 @@ enum {
     YH_OP_CONV_BWD_DATA_PAIR,
     YH_OP_FORK,   /* side lane waits for everything issued on the caller's stream so far */
     YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
-    YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT
+    YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT,
+    YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side

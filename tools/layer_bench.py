@@ -55,17 +55,22 @@ def main():
 
     fa, fn = plan.fwd_ops
     ba, bn = plan.bwd_ops
-    tf = time_ops(fa, fn, {L.OP_CONV_FWD})
-    tb = time_ops(ba, bn, {L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_WEIGHT})
+    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD})
+    DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA}
+    tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT})
     other_f = time_ops(fa, fn, {L.OP_BN_SILU_FWD, L.OP_BN_FINALIZE, L.OP_PACK_WEIGHTS, L.OP_MAXPOOL5_FWD})
     other_b = time_ops(ba, bn, {L.OP_BN_SILU_BWD_REDUCE, L.OP_BN_SILU_BWD_APPLY, L.OP_COLSUM, L.OP_MAXPOOL5_BWD})
 
     def desc(o):
         i = o.i
-        if o.kind == L.OP_CONV_FWD:
+        if o.kind == L.OP_CONV_PW_BWD_DATA:
+            return (i[5], i[6], i[7], i[8], i[0], 1, 1)
+        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_BWD_DATA):
             return (i[3], i[4], i[5], i[6], i[7], i[8], i[9])
-        if o.kind == L.OP_CONV_BWD_DATA:
-            return (i[3], i[4], i[5], i[6], i[7], i[8], i[9])
+        if o.kind == L.OP_CONV_WINO_BWD_DATA:
+            return (i[3], i[4], i[5], i[6], i[7], 3, 1)
+        if o.kind == L.OP_CONV_BWD_DATA_PAIR:      # two sibling 1x1 convs: listed under the first one's shape
+            return (i[5], i[6], i[7], i[8], i[0], 1, 1)
         return (i[2], i[3], i[4], i[5], i[7], i[8], i[9])
 
     rows = {}
@@ -74,7 +79,7 @@ def main():
         rows[desc(fa[k])][3] += 1
     for k, ms in tb.items():
         d = desc(ba[k])
-        rows.setdefault(d, [0.0, 0.0, 0.0, 0])[1 if ba[k].kind == L.OP_CONV_BWD_DATA else 2] += ms
+        rows.setdefault(d, [0.0, 0.0, 0.0, 0])[1 if ba[k].kind in DG else 2] += ms
     print(f"{'B,H,W,Cin,Cout,k,s':32s} {'n':>2s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     tot = [0.0, 0.0, 0.0, 0.0]
     for d, (f, dg, wg, cnt) in sorted(rows.items(), key=lambda kv: -(kv[1][0] + kv[1][1] + kv[1][2])):

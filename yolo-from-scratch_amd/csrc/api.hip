@@ -80,6 +80,17 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_WINO_BWD_WEIGHT:
             return yh_conv_wino_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
                                            o.l[0], i[2], i[3], i[4], i[5], i[7], st);
+        case YH_OP_CONV_PW_BWD_WEIGHT:      /* same argument slots as YH_OP_CONV_BWD_WEIGHT */
+            return yh_conv_pw_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
+                                         o.l[0], (int64_t)i[2] * i[3] * i[4], i[5], i[7], st);
+        case YH_OP_PW_PACK_MULTI:
+            return yh_pw_pack_multi(p[0], i[0], st);
+        case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */
+            return yh_conv_pw_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
+                                  (float *)p[4], (int64_t)i[3] * i[4] * i[5], i[6], i[7], st);
+        case YH_OP_CONV_PW_BWD_DATA:        /* p: dy1, dy2 | NULL, wq, dx;  i: cout1, cout2, lddy, ldw, lddx, B, H, W, Cin, accumulate */
+            return yh_conv_pw_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
+                                       (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], st);
         case YH_OP_CONV_BWD_DATA_PAIR:
             return yh_conv_bwd_data_pair((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
                                          (float *)p[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
@@ -148,7 +159,7 @@ extern "C" int yh_run(const yh_op *ops, int n, void *stream, int *failed) {
             }
             continue;
         }
-        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT || kind == YH_OP_COLSUM);
+        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT || kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_COLSUM);
         const bool side = (auto_side || ops[k].lane == 1) && side_ready();
         int rc;
         if (side) {

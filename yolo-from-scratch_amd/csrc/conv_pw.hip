@@ -1,0 +1,423 @@
+// Pointwise (1x1, stride 1) convolution kernels whose MFMA operands are loaded straight into the operand registers
+// (no LDS in the main loop), gfx950, NHWC fp32.
+//
+// Backward-weight:  dW[ci][co] = sum_p x[p][ci] * dy[p][co]  -- rows = ci, cols = co, k = pixels.  One
+// v_mfma_f32_32x32x2_f32 k-step consumes a PAIR of pixels: lane (c = lane & 31, h = lane >> 5) supplies pixel 2s+h.
+// A lane loads XV consecutive input channels and DV consecutive output channels of its pixel with one vector load
+// each; element e of the vector is the operand of row/column tile e, i.e. row r of row tile i is channel XV*r + i
+// (a fixed permutation, undone when the slab is written).  XV x DV accumulator tiles per wave, (XV + DV) loads per
+// XV*DV MFMAs.  The four waves of a workgroup walk disjoint pixel ranges of the same (ci, co) tile and are summed
+// through LDS; workgroups write [Cin][Cout] slabs that a fixed-order reduction adds up (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<1> { typedef float type; };
+template <>
+struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <>
+struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int V>
+__device__ __forceinline__ typename Vec<V>::type buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    if constexpr (V == 1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    else if constexpr (V == 2) return __builtin_bit_cast(typename Vec<2>::type, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    else return __builtin_bit_cast(typename Vec<4>::type, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+template <int V>
+__device__ __forceinline__ float vget(const typename Vec<V>::type &v, int e) {
+    if constexpr (V == 1) return v;
+    else return v[e];
+}
+
+struct PwW {
+    const float *x, *dy;
+    float *ws;
+    int ldx, lddy, Cin, Cout;
+    int M, pps;                 // pixels, pixels per split (multiple of 64)
+    unsigned x_bytes, dy_bytes;
+};
+
+template <int XV, int DV>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwW g) {
+    typedef typename Vec<XV>::type xv_t;
+    typedef typename Vec<DV>::type dv_t;
+    constexpr int SPS = 8;                     // k-steps (pixel pairs) per pipeline stage
+    constexpr int RT = 32 * XV, CT = 32 * DV;   // channels of a workgroup tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: [4][32][CT]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci0 = blockIdx.y * RT, co0 = blockIdx.z * CT;
+    // pixel range of this wave: a quarter of the split's range
+    const int p_begin = blockIdx.x * g.pps + wave * (g.pps / 4);
+    const int p_end = min(p_begin + g.pps / 4, g.M);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)g.x, 0, g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)g.dy, 0, g.dy_bytes, 0x00020000);
+    const unsigned xlane = (unsigned)(ci0 + XV * lr) * 4u, dlane = (unsigned)(co0 + DV * lr) * 4u;
+    const unsigned ldx4 = (unsigned)g.ldx * 4u, ldd4 = (unsigned)g.lddy * 4u;
+    int p = p_begin + lh;                      // this lane's pixel of the next k-step
+
+    xv_t XA[SPS], XB[SPS];
+    dv_t DA[SPS], DB[SPS];
+    auto load_stage = [&](xv_t (&X)[SPS], dv_t (&D)[SPS]) {
+#pragma unroll
+        for (int q = 0; q < SPS; ++q) {
+            const unsigned inv = (unsigned)(p >= p_end) << 31;     // bit 31: beyond num_records -> 0
+            X[q] = buf_load<XV>(rx, ((unsigned)p * ldx4 + xlane) | inv);
+            D[q] = buf_load<DV>(rd, ((unsigned)p * ldd4 + dlane) | inv);
+            p += 2;
+        }
+    };
+
+    f32x16 acc[XV][DV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i)
+#pragma unroll
+        for (int j = 0; j < DV; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](const xv_t (&X)[SPS], const dv_t (&D)[SPS]) {
+#pragma unroll
+        for (int q = 0; q < SPS; ++q)
+#pragma unroll
+            for (int i = 0; i < XV; ++i)
+#pragma unroll
+                for (int j = 0; j < DV; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<XV>(X[q], i), vget<DV>(D[q], j), acc[i][j], 0, 0, 0);
+    };
+
+    const int nstages = (g.pps / 4) / (2 * SPS);
+    load_stage(XA, DA);
+    int s = 0;
+    for (; s + 2 <= nstages; s += 2) {
+        load_stage(XB, DB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(XA, DA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(XA, DA);                    // past the range: zeros
+        __builtin_amdgcn_sched_barrier(0);
+        compute(XB, DB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s < nstages) compute(XA, DA);
+
+    // ---- sum the four waves through LDS (one row tile per pass), undo the channel permutation, write the slab ------
+    float *slab = g.ws + (size_t)blockIdx.x * g.Cin * g.Cout;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        if (i) __syncthreads();
+        float *T = smem + wave * 32 * CT;
+#pragma unroll
+        for (int j = 0; j < DV; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                T[row * CT + DV * lr + j] = acc[i][j][r];
+            }
+        __syncthreads();
+        for (int e = t; e < 32 * CT; e += 256) {
+            int col = e % CT, row = e / CT;
+            int ci = ci0 + XV * row + i, co = co0 + col;
+            if (ci < g.Cin && co < g.Cout)
+                slab[(size_t)ci * g.Cout + co] = (smem[e] + smem[32 * CT + e]) + (smem[2 * 32 * CT + e] + smem[3 * 32 * CT + e]);
+        }
+    }
+}
+
+// ws [nsplit][Cin][Cout] -> dw [Cout][Cin] (OIHW, 1x1): 16 split-lanes each add every 16th slab, lanes combined in order.
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int nsplit,
+                                                              int Cin, int Cout) {
+    __shared__ float red[16][17];
+    const int n = Cin * Cout;
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (i < n)
+        for (int k = sl; k < nsplit; k += 16) s += ws[(size_t)k * n + i];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][e];
+        int co = i % Cout, ci = i / Cout;
+        dw[(size_t)co * Cin + ci] = tot;
+    }
+}
+
+// vmax_x / vmax_d: widest vector load the operand's address and ld allow (1, 2 or 4 floats)
+int pw_plan(PwW &g, int &nsplit, int &XV, int &DV, int64_t M, int Cin, int Cout, int vmax_x, int vmax_d) {
+    YH_REQUIRE(M > 0 && M < (1ll << 30) && Cin > 0 && Cout > 0, "conv_pw_bwd_weight: bad shape");
+    g.M = (int)M; g.Cin = Cin; g.Cout = Cout;
+    XV = Cin <= 32 ? 1 : 2;                       // <= 32 channels: one tile, no wasted MFMA rows / columns
+    DV = Cout <= 32 ? 1 : (Cout % 128 == 0 ? 4 : 2);
+    while (XV > vmax_x) XV >>= 1;
+    while (DV > vmax_d) DV >>= 1;
+    int pairs = cdiv(Cin, 32 * XV) * cdiv(Cout, 32 * DV);
+    // 256 workgroups measured best on every 1x1 layer of the network (slab traffic grows with the split count)
+    static const int target = getenv("YH_PW_WGRAD_BLOCKS") ? atoi(getenv("YH_PW_WGRAD_BLOCKS")) : 256;
+    nsplit = target / pairs;
+    if (nsplit < 1) nsplit = 1;
+    int pps = cdiv(cdiv((int)M, nsplit), 64) * 64;
+    if (pps < 256) pps = 256;
+    nsplit = cdiv((int)M, pps);
+    g.pps = pps;
+    return 0;
+}
+
+int vec_width(const void *p, int ld) {
+    uintptr_t a = (uintptr_t)p;
+    if (ld % 4 == 0 && (a & 15) == 0) return 4;
+    if (ld % 2 == 0 && (a & 7) == 0) return 2;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" int64_t yh_conv_pw_bwd_weight_ws(int64_t M, int Cin, int Cout) {
+    int64_t need = 0;                              // the split count depends on the vector widths the views allow
+    for (int vx = 1; vx <= 4; vx <<= 1)
+        for (int vd = 1; vd <= 4; vd <<= 1) {
+            PwW g{};
+            int nsplit, XV, DV;
+            if (pw_plan(g, nsplit, XV, DV, M, Cin, Cout, vx, vd)) return -1;
+            if ((int64_t)nsplit * Cin * Cout > need) need = (int64_t)nsplit * Cin * Cout;
+        }
+    return need;
+}
+
+extern "C" int yh_conv_pw_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                                     int64_t M, int Cin, int Cout, void *stream) {
+    YH_REQUIRE(x && dy && dw && ws && ldx >= Cin && lddy >= Cout, "conv_pw_bwd_weight: bad argument");
+    PwW g{};
+    int nsplit, XV, DV;
+    int rc = pw_plan(g, nsplit, XV, DV, M, Cin, Cout, vec_width(x, ldx), vec_width(dy, lddy));
+    if (rc) return rc;
+    YH_REQUIRE(ws_floats >= (int64_t)nsplit * Cin * Cout, "conv_pw_bwd_weight: workspace too small");
+    YH_REQUIRE(((M - 1) * ldx + Cin) * 4 < (1ll << 31) && ((M - 1) * lddy + Cout) * 4 < (1ll << 31),
+               "conv_pw_bwd_weight: views must span less than 2 GiB");
+    g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy;
+    g.x_bytes = (unsigned)(((M - 1) * ldx + Cin) * 4);
+    g.dy_bytes = (unsigned)(((M - 1) * lddy + Cout) * 4);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nsplit, cdiv(Cin, 32 * XV), cdiv(Cout, 32 * DV));
+    const size_t smem = (size_t)4 * 32 * 32 * DV * sizeof(float);
+#define YH_PW_LAUNCH(xv, dv) hipLaunchKernelGGL((pw_wgrad_kernel<xv, dv>), grid, dim3(256), smem, st, g)
+    if (XV == 2 && DV == 4) YH_PW_LAUNCH(2, 4);
+    else if (XV == 2 && DV == 2) YH_PW_LAUNCH(2, 2);
+    else if (XV == 2) YH_PW_LAUNCH(2, 1);
+    else if (DV == 4) YH_PW_LAUNCH(1, 4);
+    else if (DV == 2) YH_PW_LAUNCH(1, 2);
+    else YH_PW_LAUNCH(1, 1);
+#undef YH_PW_LAUNCH
+    YH_CHECK_LAUNCH("pw_wgrad");
+    int n = Cin * Cout;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, ws, dw, nsplit, Cin, Cout);
+    YH_CHECK_LAUNCH("pw_wgrad_reduce");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward / backward-data of a pointwise convolution:  out[p][n] (+)= sum_k in[p][k] * W[k][n] (+ bias).
+// Rows = pixels, cols = channels.  Lane (r = lane & 31, q = lane >> 5) loads channels k0+4q .. k0+4q+3 of pixel r with
+// one float4 -- the A operand of four consecutive MFMAs (k-group = lane half) -- and the matching B fragments with one
+// float4 each from the k-quad interleaved weights Wq[K/4][ldw][4] (same layout as the Winograd U).  No LDS, no
+// barrier in the loop; two register sets, the loads of chunk c+1 are pinned ahead of the MFMAs of chunk c.
+// A wave owns TM x 32 pixels x NT x 32 channels; the four waves of a workgroup own consecutive pixel groups (their B
+// fragments are the same lines: L1 hits).  Epilogue as the other conv kernels: 128-byte row stores, bias /
+// accumulate, per-workgroup BatchNorm partial sums.  K may come from two tensors (sibling-pair backward-data).
+namespace {
+
+struct PwG {
+    const float *in, *in2, *Wq, *bias;
+    float *out, *stats;
+    int ldi, ldw, ldo;
+    int M, K, K1, N;            // K1: channels taken from `in` (the rest, K - K1, from `in2`)
+    int accumulate;
+    unsigned in_bytes, in2_bytes;
+};
+
+template <int TM, int NT>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
+    __shared__ float red[4][32 * NT][2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int p0 = (blockIdx.x * 4 + wave) * 32 * TM, n0 = blockIdx.y * 32 * NT;
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g.in, 0, g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void *)(g.in2 ? g.in2 : g.in), 0, g.in2 ? g.in2_bytes : 0u, 0x00020000);
+    unsigned aoff[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int p = p0 + i * 32 + lr;
+        aoff[i] = ((unsigned)p * (unsigned)g.ldi + 4u * lh) * 4u | ((unsigned)(p >= g.M) << 31);
+    }
+    const float *wb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int n = n0 + j * 32 + lr;
+        wb[j] = g.Wq + ((size_t)lh * g.ldw + (n < g.ldw ? n : 0)) * 4;     // columns past N are never stored
+    }
+    const size_t wchunk = (size_t)2 * g.ldw * 4;
+
+    f32x4 aA[TM], bA[NT], aB[TM], bB[NT];
+    f32x16 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](const f32x4 (&a)[TM], const f32x4 (&b)[NT]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    };
+    // one K segment (all of it from one tensor): chunks [c0, c0 + nch) of the weight rows, channels from 0 of `r`
+    auto segment = [&](const __amdgpu_buffer_rsrc_t r, int c0, int nch) {
+        auto load = [&](int c, f32x4 (&a)[TM], f32x4 (&b)[NT]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = buf_load<4>(r, aoff[i] + (unsigned)c * 32u);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *(const f32x4 *)(wb[j] + (size_t)(c0 + c) * wchunk);
+        };
+        load(0, aA, bA);
+        int c = 0;
+        for (; c + 2 <= nch; c += 2) {
+            load(c + 1, aB, bB);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(aA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            load(c + 2 < nch ? c + 2 : c, aA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(aB, bB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nch) compute(aA, bA);
+    };
+    segment(r1, 0, g.K1 / 8);
+    if (g.K > g.K1) segment(r2, g.K1 / 8, (g.K - g.K1) / 8);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 32 + lr;
+        const bool nok = n < g.N;
+        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nok && p < g.M) {
+                    float *o = g.out + (size_t)p * g.ldo + n;
+                    float v = acc[i][j][r] + bias;
+                    if (g.accumulate) v += *o;
+                    *o = v;
+                    s += v;
+                    q += v * v;
+                }
+            }
+        csum[j] = s;
+        csq[j] = q;
+    }
+    if (g.stats) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) { red[wave][j * 32 + lr][0] = s; red[wave][j * 32 + lr][1] = q; }
+        }
+        __syncthreads();
+        if (t < 32 * NT && n0 + t < g.N) {
+            float a0 = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
+            float a1 = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
+            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = a0;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = a1;
+        }
+    }
+}
+
+struct PwPackDesc {
+    const float *w;             // [Cout][Cin] (OIHW, 1x1)
+    float *wf, *wb;             // forward: Wq[Cin/4][ldwf][4]; backward-data: Wq[(koff + Cout)/4 rows...][ldwb][4]
+    int Cout, Cin, ldwf, ldwb, koff, pad;
+};
+
+// forward  Wq_f[ci >> 2][co][ci & 3] = w[co][ci];   backward  Wq_b[(koff + co) >> 2][ci][(koff + co) & 3] = w[co][ci]
+__global__ void pw_pack_multi_kernel(const PwPackDesc *__restrict__ tab) {
+    const PwPackDesc d = tab[blockIdx.y];
+    const int nf = d.wf ? d.Cin * d.ldwf : 0, nb = d.wb ? d.Cout * d.ldwb : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+        if (i < nf) {
+            int n = i % d.ldwf, k = i / d.ldwf;
+            d.wf[((size_t)(k >> 2) * d.ldwf + n) * 4 + (k & 3)] = n < d.Cout ? d.w[(size_t)n * d.Cin + k] : 0.f;
+        } else {
+            int j = i - nf;
+            int n = j % d.ldwb, k = j / d.ldwb, kk = d.koff + k;
+            d.wb[((size_t)(kk >> 2) * d.ldwb + n) * 4 + (kk & 3)] = n < d.Cin ? d.w[(size_t)k * d.Cin + n] : 0.f;
+        }
+    }
+}
+
+int launch_pw_gemm(PwG &g, hipStream_t st) {
+    YH_REQUIRE(g.K % 8 == 0 && g.K1 % 8 == 0 && g.K1 > 0 && g.K1 <= g.K && g.ldi % 4 == 0 && (((uintptr_t)g.in | (uintptr_t)g.Wq) & 15) == 0 &&
+                   (!g.in2 || (((uintptr_t)g.in2) & 15) == 0) && g.ldw >= g.N && g.M > 0,
+               "conv_pw: channels must be multiples of 8, operands 16-byte addressable");
+    YH_REQUIRE(((int64_t)(g.M - 1) * g.ldi + g.K) * 4 < (1ll << 31), "conv_pw: input view must span less than 2 GiB");
+    g.in_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + g.K1) * 4);
+    g.in2_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + (g.K - g.K1)) * 4);
+    const int NT = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
+    const int TM = (NT <= 2 && cdiv(g.M, 256) * cdiv(g.N, 32 * NT) >= 1024) ? 2 : 1;   // <2,4> would run one wave per SIMD
+    dim3 grid(cdiv(g.M, 128 * TM), cdiv(g.N, 32 * NT));
+#define YH_PWG(tm, nt) hipLaunchKernelGGL((pw_gemm_kernel<tm, nt>), grid, dim3(256), 0, st, g)
+    if (TM == 2) { if (NT == 2) YH_PWG(2, 2); else YH_PWG(2, 1); }
+    else { if (NT == 4) YH_PWG(1, 4); else if (NT == 2) YH_PWG(1, 2); else YH_PWG(1, 1); }
+#undef YH_PWG
+    YH_CHECK_LAUNCH("pw_gemm");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int yh_conv_pw_blocks(int64_t M, int Cout) {
+    const int NT = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
+    const int TM = (NT <= 2 && cdiv((int)M, 256) * cdiv(Cout, 32 * NT) >= 1024) ? 2 : 1;
+    return cdiv((int)M, 128 * TM);
+}
+
+extern "C" int yh_pw_pack_multi(const void *table, int n, void *stream) {
+    YH_REQUIRE(table && n > 0, "pw_pack_multi: bad argument");
+    static_assert(sizeof(PwPackDesc) == 48, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(pw_pack_multi_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const PwPackDesc *)table);
+    YH_CHECK_LAUNCH("pw_pack_multi");
+    return 0;
+}
+
+extern "C" int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const float *bias, float *y, int ldy,
+                              float *bn_partials, int64_t M, int Cin, int Cout, void *stream) {
+    YH_REQUIRE(x && wq && y && M > 0 && M < (1ll << 30) && ldx >= Cin && ldy >= Cout, "conv_pw_fwd: bad argument");
+    PwG g{};
+    g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = bn_partials;
+    g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
+    return launch_pw_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
+                                   float *dx, int lddx, int64_t M, int Cin, int accumulate, void *stream) {
+    YH_REQUIRE(dy1 && wq && dx && M > 0 && M < (1ll << 30) && cout1 > 0 && (dy2 ? cout2 > 0 : cout2 == 0) && lddx >= Cin,
+               "conv_pw_bwd_data: bad argument");
+    PwG g{};
+    g.in = dy1; g.in2 = dy2; g.Wq = wq; g.out = dx;
+    g.ldi = lddy; g.ldw = ldw; g.ldo = lddx; g.M = (int)M; g.K = cout1 + cout2; g.K1 = cout1; g.N = Cin; g.accumulate = accumulate;
+    return launch_pw_gemm(g, (hipStream_t)stream);
+}

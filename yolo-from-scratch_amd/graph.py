@@ -98,6 +98,9 @@ class ConvRec:
     wino_f: bool = False    # forward on the Winograd F(2x2,3x3) kernel
     wino_b: bool = False    # backward-data on the Winograd kernel
     wino_w: bool = False    # backward-weight in the Winograd domain
+    pw_w: bool = False      # backward-weight on the pointwise (1x1) kernel
+    pw_f: bool = False      # forward on the pointwise GEMM kernel
+    pw_b: bool = False      # backward-data on the pointwise GEMM kernel
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
 
@@ -216,6 +219,9 @@ class Plan:
         folds: List[tuple] = []                # inference: BN folded into the packed weights
         winos: List[tuple] = []                # Winograd weight transforms (forward and backward-data)
         use_wino = self.training and os.environ.get("YH_WINO", "1") != "0"
+        use_pw = self.training and os.environ.get("YH_PW", "1") != "0"
+        use_pwg = self.training and os.environ.get("YH_PWG", "1") != "0"
+        pwpacks: List[tuple] = []              # k-quad interleaved weights of the pointwise GEMM kernels
         if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
             # sibling pointwise convs (C3 conv1 / conv2) share one backward-data GEMM: K = Cout1 + Cout2
             groups: Dict[tuple, List[ConvRec]] = {}
@@ -255,21 +261,39 @@ class Plan:
                 r.wino_f = wino_ok and r.cin % 16 == 0 and r.cin <= 2048
                 r.wino_b = wino_ok and r.need_dx and r.cout % 16 == 0 and r.cout <= 2048
                 r.wino_w = wino_ok and r.cin % 32 == 0 and r.cout % 32 == 0 and r.x.W >= 4
+                r.pw_w = use_pw and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1]
+                # pointwise GEMM kernels: measured faster than the gather-GEMM except when both K and N are >= 256
+                pw_ok = use_pwg and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0
+                r.pw_f = pw_ok and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256)
+                if r.pair is None:
+                    r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
+                elif r.pair_first:
+                    kpair = r.cout + r.pair.cout
+                    r.pw_b = r.pair.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and r.pair.cout % 8 == 0 and \
+                        not (kpair >= 256 and r.cin >= 256)
                 if r.pair is not None and r.need_dx:
                     if r.pair_first:      # stacked backward packs: rows [0, c1) this conv, [c1, c1 + c2) its sibling
                         stacked = torch.empty((r.cout + r.pair.cout) * r.ldwb, **f32)
-                        r.wb, r.pair.wb = stacked[: r.cout * r.ldwb], stacked[r.cout * r.ldwb:]
+                        if r.pw_b:        # one k-quad interleaved matrix for both: each record writes its own K rows
+                            r.wb = r.pair.wb = stacked
+                        else:
+                            r.wb, r.pair.wb = stacked[: r.cout * r.ldwb], stacked[r.cout * r.ldwb:]
                         keep.append(stacked)
                 else:
                     r.wb = torch.empty((16 if r.wino_b else kk) * r.cout * r.ldwb, **f32) if r.need_dx else None
+                if r.pw_f or r.pw_b:
+                    koff = r.pair.cout if (r.pair is not None and not r.pair_first) else 0
+                    pwpacks.append((r.weight.data_ptr(), r.wf.data_ptr() if r.pw_f else 0, r.wb.data_ptr() if r.pw_b else 0,
+                                    r.cout, r.cin, r.ldwf, r.ldwb, koff, 0))
                 if r.wino_f:
                     r.wf = torch.empty(16 * r.cin * r.ldwf, **f32)
                     winos.append((r.weight.data_ptr(), r.wf.data_ptr(), r.cout, r.weight.shape[1], r.ldwf, 0))
                 if r.wino_b:
                     winos.append((r.weight.data_ptr(), r.wb.data_ptr(), r.cout, r.weight.shape[1], r.ldwb, 1))
-                if not (r.wino_f and (r.wino_b or r.wb is None)):
-                    packs.append((r.weight.data_ptr(), 0 if r.wino_f else r.wf.data_ptr(),
-                                  r.wb.data_ptr() if (r.wb is not None and not r.wino_b) else 0,
+                gen_f = not (r.wino_f or r.pw_f)                       # layouts the generic pack kernel still has to write
+                gen_b = r.wb is not None and not (r.wino_b or r.pw_b)
+                if gen_f or gen_b:
+                    packs.append((r.weight.data_ptr(), r.wf.data_ptr() if gen_f else 0, r.wb.data_ptr() if gen_b else 0,
                                   r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
                 r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32) if r.bn is not None else None
                 if r.bn is not None:
@@ -278,12 +302,13 @@ class Plan:
                 else:
                     ytarget, ldy = None, r.out.ld
                 nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
+                    lib.yh_conv_pw_blocks(r.x.B * r.x.H * r.x.W, r.cout) if r.pw_f else \
                     lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                 M = r.x.B * r.Ho * r.Wo
                 if r.bn is not None:
                     nb_bwd = lib.yh_bn_bwd_blocks(M, r.cout)
                     r.part = torch.empty(max(nblk, nb_bwd) * 2 * r.cout, **f32)
-                fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else L.OP_CONV_FWD,
+                fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else L.OP_CONV_FWD),
                                p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                   r.part if r.bn is not None else None],
                                i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
@@ -308,6 +333,11 @@ class Plan:
             blob = b"".join(struct.pack("<QQQQQQQQiiiiif", *d) for d in folds)
             self.fold_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             fwd.insert(0, _op(L.OP_PACK_FOLD_MULTI, p=[self.fold_table], i=[len(folds)]))
+        if pwpacks:
+            import struct
+            blob = b"".join(struct.pack("<QQQiiiiii", *d) for d in pwpacks)
+            self.pw_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            fwd.insert(0, _op(L.OP_PW_PACK_MULTI, p=[self.pw_table], i=[len(pwpacks)]))
         if winos:
             import struct
             blob = b"".join(struct.pack("<QQiiii", *d) for d in winos)
@@ -349,6 +379,7 @@ class Plan:
         for r in self.recs:
             if isinstance(r, ConvRec):
                 ws_floats = max(ws_floats, lib.yh_conv_wino_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout) if r.wino_w else
+                                lib.yh_conv_pw_bwd_weight_ws(r.x.B * r.x.H * r.x.W, r.cin, r.cout) if r.pw_w else
                                 lib.yh_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
                 if r.bias is not None:
                     ws_floats = max(ws_floats, lib.yh_colsum_ws(r.x.B * r.Ho * r.Wo, r.cout))
@@ -386,7 +417,7 @@ class Plan:
             if r.bias is not None:
                 ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
-            ops.append(_op(L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else L.OP_CONV_BWD_WEIGHT,
+            ops.append(_op(L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else (L.OP_CONV_PW_BWD_WEIGHT if r.pw_w else L.OP_CONV_BWD_WEIGHT),
                            p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
                            l=[self.ws.numel()]))
@@ -395,13 +426,20 @@ class Plan:
                 if id(r.pair) in pair_pending:      # second of the pair (in backward order): both dY are final now
                     first, second = (r, r.pair) if r.pair_first else (r.pair, r)
                     dst, acc = self._grad_target(r.x)
-                    ops.append(_op(L.OP_CONV_BWD_DATA_PAIR, p=[first.y, second.y, first.wb, dst],
-                                   i=[first.cout, second.cout, first.cout, first.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
+                    if r.pw_b:
+                        ops.append(_op(L.OP_CONV_PW_BWD_DATA, p=[first.y, second.y, first.wb, dst],
+                                       i=[first.cout, second.cout, first.cout, first.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
+                    else:
+                        ops.append(_op(L.OP_CONV_BWD_DATA_PAIR, p=[first.y, second.y, first.wb, dst],
+                                       i=[first.cout, second.cout, first.cout, first.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
                 else:
                     pair_pending.add(id(r))
             elif r.need_dx:
                 dst, acc = self._grad_target(r.x)
-                if r.wino_b:
+                if r.pw_b:
+                    ops.append(_op(L.OP_CONV_PW_BWD_DATA, p=[dy, None, r.wb, dst],
+                                   i=[r.cout, 0, lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
+                elif r.wino_b:
                     ops.append(_op(L.OP_CONV_WINO_BWD_DATA, p=[dy, r.wb, dst],
                                    i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, acc]))
                 else:
