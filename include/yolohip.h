@@ -33,6 +33,9 @@ const char *yh_last_error(void);
 /* NCHW (B,C,H,W) -> NHWC with ld floats per pixel (channels >= C are zero filled up to cpad).
  * replaces: the NCHW image batch handed to YOLO.forward (train.py:568). */
 int yh_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, int ld, int cpad, void *stream);
+/* (B,H,W,C) uint8 image batch -> NHWC fp32, value / 255.0f (true division: bit-identical to the reference's
+ * `torch.from_numpy(np.array(img)).permute(2,0,1).float() / 255.0`, train.py:115-117), channels [C, cpad) zeroed. */
+int yh_u8hwc_to_nhwc(const uint8_t *src, float *dst, int B, int H, int W, int C, int ld, int cpad, void *stream);
 /* NHWC view (C channels, ld) -> NCHW contiguous; `accumulate` adds into dst. */
 int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, int ld, int accumulate, void *stream);
 /* OIHW weights -> forward pack [kh*kw][Cin_pad][ldwf] and backward-data pack [kh*kw][Cout][ldwb];

@@ -11,12 +11,14 @@ from .inference import predict, batched_nms, Detector, InferenceSession, assign_
 from .training import train_epoch, eval_epoch, HipAdam, HipTrainer
 from .hostside import (nms, compute_iou_corners, compute_box_iou, get_lr_lambda, letterbox_resize, YOLODataset,
                        yolo_collate_fn, compute_optimal_anchors, YOLO_SIZES, stack_targets, synthetic_targets,
-                       save_checkpoint, load_checkpoint)
+                       save_checkpoint, load_checkpoint, raw_collate_fn)
+from .pipeline import DevicePrefetcher
 
 __all__ = [
     "YOLO", "ConvBlock", "C3", "Bottleneck", "SPPF", "ciou_loss", "decode_predictions", "yolo_loss",
     "yolo_loss_multiscale", "predict", "batched_nms", "Detector", "InferenceSession", "assign_targets_gpu", "train_epoch", "eval_epoch", "HipAdam",
     "HipTrainer", "nms", "compute_iou_corners", "compute_box_iou", "get_lr_lambda", "letterbox_resize",
     "YOLODataset", "yolo_collate_fn", "compute_optimal_anchors", "YOLO_SIZES", "stack_targets", "load_library",
-    "LIB_PATH", "DEFAULT_ANCHORS", "synthetic_targets", "save_checkpoint", "load_checkpoint",
+    "LIB_PATH", "DEFAULT_ANCHORS", "synthetic_targets", "save_checkpoint", "load_checkpoint", "raw_collate_fn",
+    "DevicePrefetcher",
 ]

@@ -40,6 +40,7 @@ _SIGS = {
     "yh_version": (i32, []),
     "yh_last_error": (C.c_char_p, []),
     "yh_nchw_to_nhwc": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_u8hwc_to_nhwc": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_nhwc_to_nchw": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_weights": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_weights_multi": (i32, [c_fp, i32, c_fp]),

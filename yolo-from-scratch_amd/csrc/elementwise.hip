@@ -20,6 +20,17 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__rest
     }
 }
 
+// uint8 HWC image batch -> NHWC fp32 in [0,1] (channel-padded): the reference's `from_numpy(...).float() / 255.0`
+// (train.py:115-117) evaluated on the device -- a true division, so the values are bit-identical -- 4x less PCIe traffic.
+__global__ void u8hwc_to_nhwc_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst, int C, int ld, int cpad,
+                                     int64_t npix) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t *s = src + p * C;
+        float *d = dst + p * ld;
+        for (int c = 0; c < cpad; ++c) d[c] = c < C ? (float)s[c] / 255.0f : 0.f;
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int ld,
                                     int accumulate, int64_t total) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -431,6 +442,14 @@ extern "C" int yh_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
                        H * W, ld, cpad, npix);
     YH_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int yh_u8hwc_to_nhwc(const uint8_t *src, float *dst, int B, int H, int W, int C, int ld, int cpad, void *stream) {
+    YH_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && cpad >= C && ld >= cpad, "u8hwc_to_nhwc: bad argument");
+    int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(u8hwc_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C, ld, cpad, npix);
+    YH_CHECK_LAUNCH("u8hwc_to_nhwc");
     return 0;
 }
 

@@ -46,7 +46,10 @@ class YOLODataset(Dataset):
     reference's assignment rule: best shape-IoU anchor over all nine, cell = min(int(c*G), G-1), first
     writer wins, one-hot class (train.py:60-207)."""
 
-    def __init__(self, img_dir, num_classes=1, anchors=None, img_size=640):
+    def __init__(self, img_dir, num_classes=1, anchors=None, img_size=640, raw=False):
+        # raw=True (not in the reference): __getitem__ returns (uint8 (S,S,3) image, float64 (n,5) letterboxed labels)
+        # for the device-side pipeline (pipeline.DevicePrefetcher): /255 and the target assignment run on the GPU
+        self.raw = raw
         self.imgs = sorted(glob.glob(f"{img_dir}/*.jpg") + glob.glob(f"{img_dir}/*.png"))
         self.labels = [str(Path(p).parent.parent / "labels" / f"{Path(p).stem}.txt") for p in self.imgs]
         self.num_classes, self.img_size = num_classes, img_size
@@ -74,8 +77,21 @@ class YOLODataset(Dataset):
         pil = Image.open(self.imgs[idx]).convert("RGB")
         w0, h0 = pil.size
         pil, scale, top, left = letterbox_resize(pil, self.img_size)
-        img = torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0
         S = self.img_size
+        if self.raw:
+            rows = []
+            if Path(self.labels[idx]).exists():
+                with open(self.labels[idx], encoding="utf-8") as fh:
+                    for line in fh:
+                        f = line.strip().split()
+                        if len(f) != 5:
+                            continue
+                        xc, yc, w, h = (float(v) for v in f[1:])
+                        rows.append([float(int(float(f[0]))), (xc * w0 * scale + left) / S, (yc * h0 * scale + top) / S,
+                                     (w * w0 * scale) / S, (h * h0 * scale) / S])
+            lab = torch.tensor(rows, dtype=torch.float64).reshape(-1, 5)
+            return torch.from_numpy(np.array(pil)), lab
+        img = torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0
         targets = [torch.zeros((g, g, 3, self.output_dim)) for g in self.grid_sizes]
         if Path(self.labels[idx]).exists():
             with open(self.labels[idx], encoding="utf-8") as fh:
@@ -108,8 +124,26 @@ def yolo_collate_fn(batch):
     return torch.stack([b[0] for b in batch]), [b[1] for b in batch]
 
 
+def raw_collate_fn(batch):
+    """Collate for YOLODataset(raw=True): (B,S,S,3) uint8 images, (B,maxn,5) float64 labels (zero-padded), (B,) int32
+    label counts -- a few KB of labels instead of 38 MB of dense targets per 64-image batch."""
+    imgs = torch.stack([b[0] for b in batch])
+    maxn = max(1, max(int(b[1].shape[0]) for b in batch))
+    lab = torch.zeros(len(batch), maxn, 5, dtype=torch.float64)
+    cnt = torch.zeros(len(batch), dtype=torch.int32)
+    for i, (_, l) in enumerate(batch):
+        n = int(l.shape[0])
+        cnt[i] = n
+        if n:
+            lab[i, :n] = l
+    return imgs, lab, cnt
+
+
 def stack_targets(targets, device):
-    """list[B][3] of (G,G,3,5+nc) -> three (B,G,G,3,5+nc) device tensors (train.py:900-903)."""
+    """list[B][3] of (G,G,3,5+nc) -> three (B,G,G,3,5+nc) device tensors (train.py:900-903).  Three already
+    stacked device tensors (what pipeline.DevicePrefetcher yields) pass through."""
+    if len(targets) == 3 and all(torch.is_tensor(t) and t.dim() == 5 for t in targets):
+        return [t.to(device, non_blocking=True) for t in targets]
     return [torch.stack([t[s] for t in targets]).to(device, non_blocking=True) for s in range(3)]
 
 

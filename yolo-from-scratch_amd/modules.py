@@ -95,18 +95,19 @@ class HipModule(nn.Module):
         if not x.is_cuda:
             raise RuntimeError(f"{type(self).__name__}: the HIP path needs a GPU tensor (got {x.device}); "
                                "there is no CPU fallback in this package")
-        if x.dim() != 4 or x.dtype != torch.float32:
-            raise ValueError("expected an NCHW float32 batch")
+        if x.dim() != 4 or x.dtype not in (torch.float32, torch.uint8):
+            raise ValueError("expected an NCHW float32 batch (or a (B,H,W,3) uint8 image batch)")
         L.lib()   # fail loudly if the extension is missing
         need_dx = bool(x.requires_grad and torch.is_grad_enabled())
         training = bool(self.training)
-        key = (tuple(x.shape), training, need_dx, x.device.index)
+        shape = tuple(x.shape) if x.dtype == torch.float32 else (x.shape[0], x.shape[3], x.shape[1], x.shape[2])
+        key = (shape, training, need_dx, x.device.index)
         views = self._grad_views(x.device)
         plan = self._plans.get(key)
         if plan is not None and plan.params_moved():
             plan = None
         if plan is None:
-            plan = Plan(x.device, tuple(x.shape), training, need_dx)
+            plan = Plan(x.device, shape, training, need_dx)
             self._trace(plan)
             plan.compile(views if training else None)
             self._plans[key] = plan
@@ -128,8 +129,13 @@ class HipModule(nn.Module):
     # -- boundary conversions ----------------------------------------------------------------------
     def _load_input(self, plan: Plan, x: torch.Tensor):
         x = x.contiguous()
-        B, C, H, W = x.shape
         buf = plan.input
+        if x.dtype == torch.uint8:      # (B,H,W,3) image bytes straight from the loader: /255 on the device
+            B, H, W, C = x.shape
+            L.check(L.lib().yh_u8hwc_to_nhwc(x.data_ptr(), buf.data.data_ptr(), B, H, W, C, buf.C, buf.C, _stream(x.device)),
+                    "u8hwc_to_nhwc")
+            return
+        B, C, H, W = x.shape
         L.check(L.lib().yh_nchw_to_nhwc(x.data_ptr(), buf.data.data_ptr(), B, C, H, W, buf.C, buf.C, _stream(x.device)),
                 "nchw_to_nhwc")
 
