@@ -68,8 +68,11 @@ def test_prefetcher_matches_reference_style_loader(tmp_path, nc):
     raw = DataLoader(y.YOLODataset(d, nc, img_size=S, raw=True), batch_size=4, shuffle=False, collate_fn=y.raw_collate_fn)
     ref = [(imgs, y.stack_targets(tg, "cpu")) for imgs, tg in std]
     for loader in (raw, std):                           # raw mode and pass-through mode
-        got = list(y.DevicePrefetcher(loader, dev, img_size=S, num_classes=nc, depth=2))
+        got = [(i.clone(), [t.clone() for t in tg]) for i, tg in y.DevicePrefetcher(loader, dev, img_size=S, num_classes=nc, depth=2)]
         assert len(got) == len(ref) == 3
+        dyn = list(y.DevicePrefetcher(loader, dev, img_size=S, num_classes=nc, depth=1, static_buffers=False))
+        for (gi, gt), (di, dt) in zip(got, dyn):        # fresh-tensor mode: batches may be kept without copying
+            assert torch.equal(gi, di) and all(torch.equal(a, b) for a, b in zip(gt, dt))
         for (gi, gt), (ri, rt) in zip(got, ref):
             assert gi.is_cuda and all(t.is_cuda for t in gt)
             gc = gi.cpu()                               # the reference's /255 is a CPU division: compare on the CPU
