@@ -210,3 +210,29 @@ def test_device_target_assignment_matches_reference_dataset(nc):
     dev = y.assign_targets_gpu(lab, 320, nc, torch.device("cuda"))
     for a, b_ in zip(dev, host):
         assert torch.equal(a.cpu(), b_)
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_predict_batch_equals_predict_per_image(tmp_path, nc):
+    """one batched forward + per-image candidate/NMS segments returns exactly what `predict` returns
+    image by image (images of different sizes: different letterbox parameters), including an image without detections."""
+    from PIL import Image
+    y = api()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(7)
+    paths = []
+    for i, (h, w) in enumerate(((120, 200), (260, 140), (96, 96), (300, 310))):
+        arr = rng.integers(0, 255, (h, w, 3), dtype=np.uint8) if i != 2 else np.zeros((h, w, 3), dtype=np.uint8)
+        Image.fromarray(arr).save(tmp_path / f"p{i}.png")
+        paths.append(str(tmp_path / f"p{i}.png"))
+    torch.manual_seed(11)
+    model = y.YOLO(num_classes=nc, img_size=256).to(dev)
+    model.initialize_detection_biases(prior=0.3)
+    single = [y.predict(model, p, dev, nc, conf_threshold=0.3, iou_threshold=0.4) for p in paths]
+    batch = y.predict_batch(model, paths, dev, nc, conf_threshold=0.3, iou_threshold=0.4)
+    assert len(batch) == len(single) == 4 and sum(len(d) for d in single) > 20
+    for a, b in zip(single, batch):
+        assert a == b                       # same boxes, scores, classes, order -- bit for bit
+    assert y.predict_batch(model, [], dev, nc) == []
+    again = y.predict_batch(model, paths[:2], dev, nc, conf_threshold=0.3, iou_threshold=0.4)     # smaller batch reuses buffers
+    assert again == single[:2]

@@ -7,7 +7,7 @@ Import as `yolo_from_scratch_amd` (the directory name carries a hyphen).
 from ._lib import LIB_PATH, lib as load_library
 from .modules import YOLO, ConvBlock, C3, Bottleneck, SPPF, DEFAULT_ANCHORS
 from .functional import ciou_loss, decode_predictions, yolo_loss, yolo_loss_multiscale
-from .inference import predict, batched_nms, Detector, InferenceSession, assign_targets_gpu
+from .inference import predict, predict_batch, batched_nms, Detector, InferenceSession, assign_targets_gpu
 from .training import train_epoch, eval_epoch, HipAdam, HipTrainer
 from .hostside import (nms, compute_iou_corners, compute_box_iou, get_lr_lambda, letterbox_resize, YOLODataset,
                        yolo_collate_fn, compute_optimal_anchors, YOLO_SIZES, stack_targets, synthetic_targets,
@@ -16,7 +16,7 @@ from .pipeline import DevicePrefetcher
 
 __all__ = [
     "YOLO", "ConvBlock", "C3", "Bottleneck", "SPPF", "ciou_loss", "decode_predictions", "yolo_loss",
-    "yolo_loss_multiscale", "predict", "batched_nms", "Detector", "InferenceSession", "assign_targets_gpu", "train_epoch", "eval_epoch", "HipAdam",
+    "yolo_loss_multiscale", "predict", "predict_batch", "batched_nms", "Detector", "InferenceSession", "assign_targets_gpu", "train_epoch", "eval_epoch", "HipAdam",
     "HipTrainer", "nms", "compute_iou_corners", "compute_box_iou", "get_lr_lambda", "letterbox_resize",
     "YOLODataset", "yolo_collate_fn", "compute_optimal_anchors", "YOLO_SIZES", "stack_targets", "load_library",
     "LIB_PATH", "DEFAULT_ANCHORS", "synthetic_targets", "save_checkpoint", "load_checkpoint", "raw_collate_fn",

@@ -105,6 +105,36 @@ def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_th
     return det.fetch()
 
 
+def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_threshold=0.4):
+    """`predict` for several images at once: ONE batched forward, then candidate extraction and
+    class-aware NMS per image segment (each image keeps its own letterbox parameters and its own candidate set, so
+    nothing is suppressed across images); one host synchronisation at the end.  `images`: paths or PIL images.
+    Returns a list with, per image, exactly what `predict(model, image, ...)` returns (same boxes, scores, order)."""
+    from PIL import Image
+    model.eval()
+    S = model.img_size
+    xs, meta = [], []
+    for im in images:
+        pil = im if isinstance(im, Image.Image) else Image.open(im)
+        pil, scale, pad_top, pad_left = letterbox_resize(pil.convert("RGB"), S)
+        xs.append(torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0)
+        meta.append((pad_left, pad_top, scale))
+    if not xs:
+        return []
+    x = torch.stack(xs).to(device)
+    with torch.no_grad():
+        preds = model(x)
+    grids = [p.shape[1] for p in preds]
+    dets = getattr(model, "_detectors", None)
+    if dets is None or len(dets) < len(xs) or dets[0].grids != grids or dets[0].nc != num_classes or dets[0].device != preds[0].device:
+        dets = [Detector(grids, num_classes, preds[0].device) for _ in xs]
+        model._detectors = dets
+    for b, (pad_left, pad_top, scale) in enumerate(meta):
+        dets[b].candidates([p[b:b + 1] for p in preds], model.anchors, S, conf_threshold, pad_left, pad_top, scale)
+        dets[b].nms(iou_threshold)
+    return [dets[b].fetch() for b in range(len(xs))]
+
+
 class InferenceSession:
     """bs=1 end-to-end inference (BASELINE config 5): NCHW->NHWC, BN-folded fused convs, candidate
     extraction and global NMS, captured ONCE into a hipGraph (via torch.cuda.CUDAGraph on the launch
