@@ -192,6 +192,10 @@ def main():
                               "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0), 3),
                               "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
                               "launches_per_step": n_launch,
+                              # north_star's target quantity: the whole Conv+BN+SiLU forward (conv kernels + statistics
+                              # finalize + normalise/SiLU pass) against the same peak
+                              "conv_bn_silu_forward_ms_per_step": round(conv_ms + per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BN_SILU_FWD, 0.0), 3),
+                              "conv_bn_silu_forward_frac": round(flops / ((conv_ms + per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BN_SILU_FWD, 0.0)) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                               "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
         result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
