@@ -75,6 +75,12 @@ int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float
  * dy1 / dy2: (B,H,W,*) views with the same ld; wb: the two backward packs stacked, rows [0,cout1) then [cout1, cout1+cout2). */
 int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wb, int ldwb,
                           float *dx, int lddx, int B, int H, int W, int Cin, int accumulate, void *stream);
+/* The network's first convolution (3 -> 16 channels, k = 3, s = 2, p = 1, input NHWC4 with ld = 4, forward pack weights
+ * [9][4][16]) as a direct VALU kernel: the layer is HBM-bound and K = 27 is too small for the MFMA path.  Same contract as
+ * yh_conv_fwd; bn_partials [yh_conv_stem_blocks(B,Hi,Wi)][2][16].  replaces: stem[0] forward, train.py:402-403. */
+int yh_conv_stem_fwd(const float *x, const float *wf, const float *bias, float *y, int ldy, float *bn_partials, int B, int Hi,
+                     int Wi, void *stream);
+int yh_conv_stem_blocks(int B, int Hi, int Wi);
 /* Winograd F(2x2,3x3) path for 3x3 / stride-1 / pad-1 convolutions with even H, W and K % 16 == 0 (K = Cin forward,
  * Cout backward): the same results as yh_conv_fwd / yh_conv_bwd_data to fp32 rounding with 4/9 of the multiplies.
  * yh_wino_weights transforms OIHW weights into U[16][K][ldu] (backward = 0: K = Cin, N = Cout; backward = 1: the
@@ -262,7 +268,8 @@ enum {
     YH_OP_FORK,   /* side lane waits for everything issued on the caller's stream so far */
     YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
     YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT,
-    YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA
+    YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA,
+    YH_OP_CONV_STEM_FWD
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side

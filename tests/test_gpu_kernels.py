@@ -267,3 +267,37 @@ def test_fused_inference_conv_with_folded_bn(Cin, Cout, k, s, res, up, act):
     L.check(lib.yh_conv_fwd_fused(xg.data_ptr(), Cin, wf.data_ptr(), ldwf, fb.data_ptr(), rg.data_ptr() if res else None, Cout,
                                   out.data_ptr(), Cout, B, H, W, Cin, Cout, k, s, int(act), int(up), st))
     assert rel_err(out.permute(0, 3, 1, 2), y) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 50, 38), (3, 33, 47)])
+def test_stem_conv_direct_kernel(B, H, W):
+    """yh_conv_stem_fwd (first layer, 3->16, k3 s2 p1, NHWC4 input) against fp64 torch and against the generic kernel's
+    BatchNorm partial-sum contract; odd sizes and a ragged last workgroup included."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(B * 100 + H)
+    x = torch.randn(B, 3, H, W)
+    w = torch.randn(16, 3, 3, 3) / 27 ** 0.5
+    bias = torch.randn(16)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), 2, 1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    st = torch.cuda.current_stream().cuda_stream
+    x4 = torch.zeros(B, H, W, 4, device="cuda")
+    x4[..., :3] = x.permute(0, 2, 3, 1).cuda()
+    wf = torch.empty(9 * 4 * 16, device="cuda")
+    L.check(lib.yh_pack_weights(w.cuda().data_ptr(), wf.data_ptr(), None, 16, 3, 3, 4, 16, 4, st))
+    ldy = 24
+    y = torch.full((B, Ho, Wo, ldy), -1.0, device="cuda")
+    nblk = lib.yh_conv_stem_blocks(B, H, W)
+    part = torch.zeros(nblk, 2, 16, device="cuda")
+    L.check(lib.yh_conv_stem_fwd(x4.data_ptr(), wf.data_ptr(), bias.cuda().data_ptr(), y.data_ptr(), ldy, part.data_ptr(), B, H, W, st))
+    out = y[..., :16].permute(0, 3, 1, 2)
+    assert rel_err(out, ref) < 1e-5
+    assert float(y[..., 16:].min()) == -1.0 == float(y[..., 16:].max())
+    s = part.double().sum(0).cpu()
+    od = out.double().cpu()
+    assert float((s[0] - od.sum((0, 2, 3))).abs().max() / od.sum((0, 2, 3)).abs().max()) < 1e-5
+    assert float((s[1] - (od * od).sum((0, 2, 3))).abs().max() / (od * od).sum((0, 2, 3)).abs().max()) < 1e-5
+    y2 = torch.empty(B, Ho, Wo, 16, device="cuda")
+    L.check(lib.yh_conv_stem_fwd(x4.data_ptr(), wf.data_ptr(), None, y2.data_ptr(), 16, None, B, H, W, st))
+    assert rel_err(y2.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, 2, 1)) < 1e-5

@@ -83,6 +83,9 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_PW_BWD_WEIGHT:      /* same argument slots as YH_OP_CONV_BWD_WEIGHT */
             return yh_conv_pw_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
                                          o.l[0], (int64_t)i[2] * i[3] * i[4], i[5], i[7], st);
+        case YH_OP_CONV_STEM_FWD:           /* same argument slots as YH_OP_CONV_FWD */
+            return yh_conv_stem_fwd((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[2], (float *)p[4],
+                                    i[3], i[4], i[5], st);
         case YH_OP_PW_PACK_MULTI:
             return yh_pw_pack_multi(p[0], i[0], st);
         case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */

@@ -178,10 +178,11 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, dou
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
                                    float *__restrict__ coef, int C, int64_t *__restrict__ nbt) {
-    __shared__ double rs[4], rq[4];
+    __shared__ double rs[16], rq[16];
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = t; b < nblk; b += blockDim.x) {
+#pragma unroll 4
+    for (int b = t; b < nblk; b += blockDim.x) {     // latency-bound strided reads: many threads, loads kept in flight
         s += (double)part[((size_t)b * 2 + 0) * C + c];
         q += (double)part[((size_t)b * 2 + 1) * C + c];
     }
@@ -190,7 +191,8 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, dou
     if ((t & 63) == 0) { rs[t >> 6] = s; rq[t >> 6] = q; }
     __syncthreads();
     if (t == 0) {
-        double S = rs[0] + rs[1] + rs[2] + rs[3], Q = rq[0] + rq[1] + rq[2] + rq[3];
+        double S = 0.0, Q = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { S += rs[w]; Q += rq[w]; }
         double mean = S / count, var = Q / count - mean * mean;
         if (var < 0.0) var = 0.0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -311,9 +313,10 @@ __global__ void bn_silu_bwd_reduce_kernel(const float *__restrict__ da, int ldda
 // totals of the partials -> dbeta (sum dz) and dgamma (sum dz*xhat); one workgroup per channel
 __global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, int C) {
-    __shared__ double rs[4], rq[4];
+    __shared__ double rs[16], rq[16];
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
+#pragma unroll 4
     for (int b = t; b < nblk; b += blockDim.x) {
         s += (double)part[((size_t)b * 2 + 0) * C + c];
         q += (double)part[((size_t)b * 2 + 1) * C + c];
@@ -323,8 +326,10 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk,
     if ((t & 63) == 0) { rs[t >> 6] = s; rq[t >> 6] = q; }
     __syncthreads();
     if (t == 0) {
-        dbeta[c] = (float)(rs[0] + rs[1] + rs[2] + rs[3]);
-        dgamma[c] = (float)(rq[0] + rq[1] + rq[2] + rq[3]);
+        double S = 0.0, Q = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { S += rs[w]; Q += rq[w]; }
+        dbeta[c] = (float)S;
+        dgamma[c] = (float)Q;
     }
 }
 
@@ -516,7 +521,7 @@ extern "C" int yh_bn_finalize(const float *partials, int nblk, int64_t count, co
                               float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
                               int64_t *num_batches_tracked, void *stream) {
     YH_REQUIRE(partials && gamma && beta && coef && nblk > 0 && count > 0 && C > 0, "bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, (double)count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, (double)count,
                        gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked);
     YH_CHECK_LAUNCH("bn_finalize");
     return 0;
@@ -576,7 +581,7 @@ extern "C" int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, i
     (void)gamma;
     YH_REQUIRE(da && y && coef && partials && dgamma && dbeta && dy && M > 0 && nblk > 0, "bn_silu_bwd_apply: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_apply", C, ldda, ldy, lddy, dres ? lddres : 0);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
                        C);
     YH_CHECK_LAUNCH("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,

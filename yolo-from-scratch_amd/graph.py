@@ -100,6 +100,7 @@ class ConvRec:
     wino_w: bool = False    # backward-weight in the Winograd domain
     pw_w: bool = False      # backward-weight on the pointwise (1x1) kernel
     pw_f: bool = False      # forward on the pointwise GEMM kernel
+    stem_f: bool = False    # forward on the direct VALU kernel of the first layer
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
@@ -221,6 +222,7 @@ class Plan:
         use_wino = self.training and os.environ.get("YH_WINO", "1") != "0"
         use_pw = self.training and os.environ.get("YH_PW", "1") != "0"
         use_pwg = self.training and os.environ.get("YH_PWG", "1") != "0"
+        use_stem = self.training and os.environ.get("YH_STEM", "1") != "0"
         pwpacks: List[tuple] = []              # k-quad interleaved weights of the pointwise GEMM kernels
         if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
             # sibling pointwise convs (C3 conv1 / conv2) share one backward-data GEMM: K = Cout1 + Cout2
@@ -265,6 +267,7 @@ class Plan:
                 # pointwise GEMM kernels: measured faster than the gather-GEMM except when both K and N are >= 256
                 pw_ok = use_pwg and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0
                 r.pw_f = pw_ok and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256)
+                r.stem_f = use_stem and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16
                 if r.pair is None:
                     r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
                 elif r.pair_first:
@@ -303,12 +306,13 @@ class Plan:
                     ytarget, ldy = None, r.out.ld
                 nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
                     lib.yh_conv_pw_blocks(r.x.B * r.x.H * r.x.W, r.cout) if r.pw_f else \
+                    lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
                     lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                 M = r.x.B * r.Ho * r.Wo
                 if r.bn is not None:
                     nb_bwd = lib.yh_bn_bwd_blocks(M, r.cout)
                     r.part = torch.empty(max(nblk, nb_bwd) * 2 * r.cout, **f32)
-                fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else L.OP_CONV_FWD),
+                fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else (L.OP_CONV_STEM_FWD if r.stem_f else L.OP_CONV_FWD)),
                                p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                   r.part if r.bn is not None else None],
                                i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
