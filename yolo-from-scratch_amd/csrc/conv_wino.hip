@@ -32,6 +32,7 @@ struct Wino {
     int ldi, ldu, ldo;
     int B, H, W, K, N;
     int TW, TPI, ntiles;        // tile columns per row, tiles per image, total tiles
+    int ncol;                   // column blocks (set by the launcher)
     int accumulate;
     unsigned tw_magic, tpi_magic;
     int tw_shift, tpi_shift;
@@ -51,7 +52,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int tile0 = blockIdx.x * TPB, n0 = blockIdx.y * BNW;
+    // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): remap the linear id so that every
+    // XCD walks a contiguous range of (tile group, column block) pairs with the column blocks of one tile group
+    // adjacent -- the halo rows shared by vertically adjacent tile groups and the input re-read by the other column
+    // blocks then hit that XCD's L2 instead of going out to the fabric.  Bijective for any grid size.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tgrp = lin / g.ncol, colb = lin - tgrp * g.ncol;
+    const int tile0 = tgrp * TPB, n0 = colb * BNW;
 
     // rows of the 4x4 input patch that transform row xi = wave combines: t = d[ra] + sg * d[rb]
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
@@ -199,8 +208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int w = 0; w < TG; ++w) { a0 += red[(w * BNW + t) * 2]; a1 += red[(w * BNW + t) * 2 + 1]; }
-            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = a0;
-            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = a1;
+            g.stats[((size_t)tgrp * 2 + 0) * g.N + n0 + t] = a0;
+            g.stats[((size_t)tgrp * 2 + 1) * g.N + n0 + t] = a1;
         }
     }
 }
@@ -479,15 +488,16 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
 }
 
 template <int NT, int PIPE>
-int launch_nt(const Wino &g, hipStream_t st) {
+int launch_nt(Wino &g, hipStream_t st) {
     constexpr int BNW = 32 * NT;
+    g.ncol = cdiv(g.N, BNW);
     constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         YH_HIP(hipFuncSetAttribute((const void *)wino_kernel<NT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
-    hipLaunchKernelGGL((wino_kernel<NT, PIPE>), dim3(cdiv(g.ntiles, TPB), cdiv(g.N, BNW)), dim3(256), smem, st, g);
+    hipLaunchKernelGGL((wino_kernel<NT, PIPE>), dim3(cdiv(g.ntiles, TPB) * g.ncol), dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("wino");
     return 0;
 }
