@@ -200,9 +200,11 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "traffic_note": "bytes per step over the same 62 launches (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.json); algorithmic 8.41e9",
-                              "kernel": "forward convolutions: gather_gemm_kernel (1x1, stride-2, stem) + wino_kernel (3x3 stride-1, "
-                                        "Winograd F(2x2,3x3): executes 4/9 of the algorithmic multiplies)",
+                              "traffic_note": "HBM-side bytes per step over the same 62 launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                                              "profiles/r01_hbm_traffic.json, tools/hbm_traffic.py); algorithmic 8.41e9",
+                              "kernel": "forward convolutions: wino_kernel (22 3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
+                                        "the algorithmic multiplies) + pw_gemm_kernel (1x1) + gather_gemm_kernel (stride-2, "
+                                        "wide 1x1, head outputs) + stem_conv_kernel (first layer, VALU)",
                               "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
                               "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
                               "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0), 3),
