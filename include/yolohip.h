@@ -70,6 +70,12 @@ int yh_pack_fold_multi(const void *table, int n_layers, void *stream);
  * gradient) reached from loss.backward() (train.py:913). */
 int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi,
                      int Wi, int Cin, int Cout, int k, int s, int accumulate, void *stream);
+/* Stride-2 3x3 backward-data with the two column parities merged into the channel axis (narrow layers, Cin <= 32): dx must
+ * be pixel-dense (lddx == Cin) with an even width; wbm = yh_pack_weights_s2m(oihw): [kh 3][c 2][Cout][ldw >= 2*Cin].
+ * Same result as yh_conv_bwd_data(k = 3, s = 2); replaces the input gradient of stem[3], train.py:407. */
+int yh_conv_bwd_data_s2m(const float *dy, int lddy, const float *wbm, int ldw, float *dx, int lddx, int B, int Hi, int Wi,
+                         int Cin, int Cout, int accumulate, void *stream);
+int yh_pack_weights_s2m(const float *oihw, float *wbm, int Cout, int Cin, int ldw, void *stream);
 /* Backward-data of TWO pointwise (1x1, stride 1) convolutions that share their input (C3's conv1 / conv2):
  * dx (+)= dy1 * W1^T + dy2 * W2^T as one GEMM over K = cout1 + cout2 (dx written once, no read-modify-write).
  * dy1 / dy2: (B,H,W,*) views with the same ld; wb: the two backward packs stacked, rows [0,cout1) then [cout1, cout1+cout2). */
@@ -269,7 +275,7 @@ enum {
     YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
     YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT,
     YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA,
-    YH_OP_CONV_STEM_FWD
+    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side

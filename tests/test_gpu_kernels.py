@@ -301,3 +301,34 @@ def test_stem_conv_direct_kernel(B, H, W):
     y2 = torch.empty(B, Ho, Wo, 16, device="cuda")
     L.check(lib.yh_conv_stem_fwd(x4.data_ptr(), wf.data_ptr(), None, y2.data_ptr(), 16, None, B, H, W, st))
     assert rel_err(y2.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, 2, 1)) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 16, 32), (1, 17, 22, 16, 32), (2, 10, 12, 8, 24), (1, 8, 8, 32, 64)])
+def test_stride2_backward_data_merged_parities(B, H, W, Cin, Cout):
+    """yh_conv_bwd_data_s2m (column parities merged into the channel axis) = the input gradient of a 3x3 stride-2 conv:
+    against fp64 torch and the generic four-class kernel; odd heights, accumulate."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(H * 7 + Cin)
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, Cout, Ho, Wo)
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double(), stride=2, padding=1)
+    st = torch.cuda.current_stream().cuda_stream
+    ldw = rup4(2 * Cin)
+    wbm = torch.empty(6 * Cout * ldw, device="cuda")
+    L.check(lib.yh_pack_weights_s2m(w.cuda().data_ptr(), wbm.data_ptr(), Cout, Cin, ldw, st))
+    dyd = nhwc(dy)
+    dx = torch.full((B, H, W, Cin), 3.0, device="cuda")
+    L.check(lib.yh_conv_bwd_data_s2m(dyd.data_ptr(), Cout, wbm.data_ptr(), ldw, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 0, st))
+    assert rel_err(dx.permute(0, 3, 1, 2), ref) < 1e-4
+    L.check(lib.yh_conv_bwd_data_s2m(dyd.data_ptr(), Cout, wbm.data_ptr(), ldw, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 1, st))
+    assert rel_err(dx.permute(0, 3, 1, 2), 2 * ref) < 1e-4
+    wb = torch.empty(9 * Cout * rup4(Cin), device="cuda")
+    L.check(lib.yh_pack_weights(w.cuda().data_ptr(), None, wb.data_ptr(), Cout, Cin, 3, Cin, rup4(Cout), rup4(Cin), st))
+    dx2 = torch.empty(B, H, W, Cin, device="cuda")
+    L.check(lib.yh_conv_bwd_data(dyd.data_ptr(), Cout, wb.data_ptr(), rup4(Cin), dx2.data_ptr(), Cin, B, H, W, Cin, Cout, 3, 2, 0, st))
+    dx3 = torch.empty(B, H, W, Cin, device="cuda")
+    L.check(lib.yh_conv_bwd_data_s2m(dyd.data_ptr(), Cout, wbm.data_ptr(), ldw, dx3.data_ptr(), Cin, B, H, W, Cin, Cout, 0, st))
+    assert rel_err(dx3, dx2) < 1e-5
+    assert lib.yh_conv_bwd_data_s2m(dyd.data_ptr(), Cout, wbm.data_ptr(), ldw, dx3.data_ptr(), Cin + 4, B, H, W, Cin, Cout, 0, st) != 0

@@ -56,7 +56,7 @@ def main():
     fa, fn = plan.fwd_ops
     ba, bn = plan.bwd_ops
     tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD})
-    DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA}
+    DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA, L.OP_CONV_BWD_DATA_S2M}
     tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT})
     other_f = time_ops(fa, fn, {L.OP_BN_SILU_FWD, L.OP_BN_FINALIZE, L.OP_PACK_WEIGHTS, L.OP_MAXPOOL5_FWD})
     other_b = time_ops(ba, bn, {L.OP_BN_SILU_BWD_REDUCE, L.OP_BN_SILU_BWD_APPLY, L.OP_COLSUM, L.OP_MAXPOOL5_BWD})
@@ -65,7 +65,7 @@ def main():
         i = o.i
         if o.kind == L.OP_CONV_PW_BWD_DATA:
             return (i[5], i[6], i[7], i[8], i[0], 1, 1)
-        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD, L.OP_CONV_BWD_DATA):
+        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD, L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_DATA_S2M):
             return (i[3], i[4], i[5], i[6], i[7], i[8], i[9])
         if o.kind == L.OP_CONV_WINO_BWD_DATA:
             return (i[3], i[4], i[5], i[6], i[7], 3, 1)

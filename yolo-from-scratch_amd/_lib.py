@@ -29,7 +29,7 @@ class YhOp(C.Structure):
  OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI, OP_PACK_FOLD_MULTI,
  OP_CONV_FWD_FUSED, OP_CONV_BWD_DATA_PAIR, OP_FORK, OP_JOIN, OP_WINO_WEIGHTS_MULTI, OP_CONV_WINO_FWD,
  OP_CONV_WINO_BWD_DATA, OP_CONV_WINO_BWD_WEIGHT, OP_CONV_PW_BWD_WEIGHT, OP_PW_PACK_MULTI, OP_CONV_PW_FWD,
- OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD) = range(1, 32)
+ OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M) = range(1, 34)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -55,6 +55,8 @@ _SIGS = {
     "yh_conv_wino_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32]),
+    "yh_conv_bwd_data_s2m": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_pack_weights_s2m": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "yh_conv_stem_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
     "yh_conv_stem_blocks": (i32, [i32, i32, i32]),
     "yh_pw_pack_multi": (i32, [c_fp, i32, c_fp]),

@@ -86,6 +86,11 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_STEM_FWD:           /* same argument slots as YH_OP_CONV_FWD */
             return yh_conv_stem_fwd((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[2], (float *)p[4],
                                     i[3], i[4], i[5], st);
+        case YH_OP_PACK_WEIGHTS_S2M:
+            return yh_pack_weights_s2m((const float *)p[0], (float *)p[1], i[0], i[1], i[2], st);
+        case YH_OP_CONV_BWD_DATA_S2M:       /* same argument slots as YH_OP_CONV_BWD_DATA */
+            return yh_conv_bwd_data_s2m((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4], i[5],
+                                        i[6], i[7], i[10], st);
         case YH_OP_PW_PACK_MULTI:
             return yh_pw_pack_multi(p[0], i[0], st);
         case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */

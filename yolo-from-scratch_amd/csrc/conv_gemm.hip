@@ -499,6 +499,46 @@ extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int 
     }
 }
 
+// Stride-2 3x3 backward-data with the two column parities MERGED into the channel axis (for narrow layers: Cin <= 32).
+// dx is dense in pixels (lddx == Cin), so the pixel pair (2q, 2q+1) of a row is 2*Cin contiguous floats: view dx as
+// (B, Hi, Wi/2, 2*Cin) and compute, per row parity ph, out[(y, q)][(pw, ci)] from the dy pixels (oy, q) and (oy, q+1):
+//   ph = 0: kh = 1, oy = y/2;   ph = 1: kh = 0 -> oy + 1, kh = 2 -> oy
+//   pw = 0: kw = 1 from column q;   pw = 1: kw = 2 from column q, kw = 0 from column q + 1
+// The merged weights W'[kh][c][co][(pw, ci)] (yh_pack_weights_s2m) hold zero blocks where a (column, parity) pair has no
+// tap: 4/3 of the exact multiplies, but N doubles (no half-empty MFMA column tiles at Cin = 16), stores are full
+// 128-byte lines instead of every other pixel, and two classes instead of four share the launch.
+extern "C" int yh_conv_bwd_data_s2m(const float *dy, int lddy, const float *wbm, int ldw, float *dx, int lddx, int B, int Hi,
+                                    int Wi, int Cin, int Cout, int accumulate, void *stream) {
+    YH_REQUIRE(dy && wbm && dx && B > 0 && Cin > 0 && Cout > 0 && Hi > 0, "conv_bwd_data_s2m: bad argument");
+    YH_REQUIRE(lddx == Cin && Wi % 2 == 0 && lddy >= Cout && ldw >= 2 * Cin, "conv_bwd_data_s2m: needs a pixel-dense dx and an even width");
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    GatherGemmSet gs{};
+    int ncls = 0;
+    for (int ph = 0; ph < 2; ++ph) {
+        GatherGemm g{};
+        g.in = dy; g.w = wbm; g.bias = nullptr; g.out = dx; g.stats = nullptr;
+        g.Hi = Ho; g.Wi = Wo; g.ldi = lddy; g.Cin = Cout; g.ldw = ldw;
+        g.Ho_f = Hi; g.Wo_f = Wi / 2; g.ldo = 2 * lddx; g.N = 2 * Cin;
+        g.B = B; g.Yo = (Hi - ph + 1) / 2; g.Xo = Wi / 2; g.M = B * g.Yo * g.Xo;
+        g.osy = 2; g.osx = 1; g.ooy = ph; g.oox = 0; g.sy = g.sx = 1;
+        g.accumulate = accumulate; g.dense = 0;
+        int nt = 0;
+        for (int kh = 0; kh < 3; ++kh) {
+            if ((ph + 1 - kh) % 2 != 0) continue;
+            for (int c = 0; c < 2; ++c) {
+                g.tap_dy[nt] = (ph + 1 - kh) / 2; g.tap_dx[nt] = c; g.tap_w[nt] = kh * 2 + c;
+                ++nt;
+            }
+        }
+        g.nTaps = nt; g.Ktot = nt * Cout;
+        if (g.M == 0) continue;
+        gs.c[ncls++] = g;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (ncls == 0) return 0;
+    return ncls == 1 ? launch_set<1>(gs, st) : launch_set<2>(gs, st);
+}
+
 // Backward-data of two pointwise (1x1, stride 1) convolutions that read the SAME input x (the conv1 / conv2 pair
 // of a C3 block): dx (+)= dy1 * W1^T + dy2 * W2^T as ONE GEMM with K = Cout1 + Cout2, so dx is written once
 // instead of written and then read-modified-written.  wb holds the two backward packs stacked: rows [0, Cout1)

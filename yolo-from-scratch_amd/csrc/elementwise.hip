@@ -468,6 +468,31 @@ extern "C" int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H
     return 0;
 }
 
+// merged stride-2 backward pack: W'[kh][c][co][pw*Cin + ci], see yh_conv_bwd_data_s2m
+__global__ void pack_weights_s2m_kernel(const float *__restrict__ w, float *__restrict__ wbm, int Cout, int Cin, int ldw) {
+    const int total = 6 * Cout * ldw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int n = i % ldw, q = i / ldw;
+        int co = q % Cout, t = q / Cout;
+        int c = t & 1, kh = t >> 1;
+        float v = 0.f;
+        if (n < 2 * Cin) {
+            int pw = n / Cin, ci = n - pw * Cin;
+            int kw = pw == 0 ? (c == 0 ? 1 : -1) : (c == 0 ? 2 : 0);
+            if (kw >= 0) v = w[((size_t)co * Cin + ci) * 9 + kh * 3 + kw];
+        }
+        wbm[i] = v;
+    }
+}
+
+extern "C" int yh_pack_weights_s2m(const float *oihw, float *wbm, int Cout, int Cin, int ldw, void *stream) {
+    YH_REQUIRE(oihw && wbm && Cout > 0 && Cin > 0 && ldw >= 2 * Cin && ldw % 4 == 0, "pack_weights_s2m: bad argument");
+    hipLaunchKernelGGL(pack_weights_s2m_kernel, dim3(grid_for((int64_t)6 * Cout * ldw)), dim3(256), 0, (hipStream_t)stream, oihw, wbm,
+                       Cout, Cin, ldw);
+    YH_CHECK_LAUNCH("pack_weights_s2m");
+    return 0;
+}
+
 extern "C" int yh_pack_weights(const float *oihw, float *wf, float *wb, int Cout, int Cin, int k, int cin_pad,
                                int ldwf, int ldwb, void *stream) {
     YH_REQUIRE(oihw && (wf || wb) && cin_pad >= Cin, "pack_weights: bad argument");

@@ -101,6 +101,7 @@ class ConvRec:
     pw_w: bool = False      # backward-weight on the pointwise (1x1) kernel
     pw_f: bool = False      # forward on the pointwise GEMM kernel
     stem_f: bool = False    # forward on the direct VALU kernel of the first layer
+    s2m_b: bool = False     # stride-2 backward-data with the column parities merged into the channel axis
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
@@ -223,6 +224,8 @@ class Plan:
         use_pw = self.training and os.environ.get("YH_PW", "1") != "0"
         use_pwg = self.training and os.environ.get("YH_PWG", "1") != "0"
         use_stem = self.training and os.environ.get("YH_STEM", "1") != "0"
+        use_s2m = self.training and os.environ.get("YH_S2M", "1") != "0"
+        s2m_packs: List[L.YhOp] = []
         pwpacks: List[tuple] = []              # k-quad interleaved weights of the pointwise GEMM kernels
         if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
             # sibling pointwise convs (C3 conv1 / conv2) share one backward-data GEMM: K = Cout1 + Cout2
@@ -267,6 +270,8 @@ class Plan:
                 # pointwise GEMM kernels: measured faster than the gather-GEMM except when both K and N are >= 256
                 pw_ok = use_pwg and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0
                 r.pw_f = pw_ok and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256)
+                r.s2m_b = use_s2m and r.k == 3 and r.s == 2 and r.need_dx and r.cin <= 16 and r.x.ld == r.cin and r.x.W % 2 == 0 \
+                    and r.cin == r.weight.shape[1]
                 r.stem_f = use_stem and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16
                 if r.pair is None:
                     r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
@@ -282,6 +287,10 @@ class Plan:
                         else:
                             r.wb, r.pair.wb = stacked[: r.cout * r.ldwb], stacked[r.cout * r.ldwb:]
                         keep.append(stacked)
+                elif r.s2m_b:
+                    r.ldwb = _rup4(2 * r.cin)
+                    r.wb = torch.empty(6 * r.cout * r.ldwb, **f32)
+                    s2m_packs.append(_op(L.OP_PACK_WEIGHTS_S2M, p=[r.weight, r.wb], i=[r.cout, r.cin, r.ldwb]))
                 else:
                     r.wb = torch.empty((16 if r.wino_b else kk) * r.cout * r.ldwb, **f32) if r.need_dx else None
                 if r.pw_f or r.pw_b:
@@ -294,7 +303,7 @@ class Plan:
                 if r.wino_b:
                     winos.append((r.weight.data_ptr(), r.wb.data_ptr(), r.cout, r.weight.shape[1], r.ldwb, 1))
                 gen_f = not (r.wino_f or r.pw_f)                       # layouts the generic pack kernel still has to write
-                gen_b = r.wb is not None and not (r.wino_b or r.pw_b)
+                gen_b = r.wb is not None and not (r.wino_b or r.pw_b or r.s2m_b)
                 if gen_f or gen_b:
                     packs.append((r.weight.data_ptr(), r.wf.data_ptr() if gen_f else 0, r.wb.data_ptr() if gen_b else 0,
                                   r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
@@ -337,6 +346,8 @@ class Plan:
             blob = b"".join(struct.pack("<QQQQQQQQiiiiif", *d) for d in folds)
             self.fold_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             fwd.insert(0, _op(L.OP_PACK_FOLD_MULTI, p=[self.fold_table], i=[len(folds)]))
+        for o in s2m_packs:
+            fwd.insert(0, o)
         if pwpacks:
             import struct
             blob = b"".join(struct.pack("<QQQiiiiii", *d) for d in pwpacks)
@@ -440,7 +451,10 @@ class Plan:
                     pair_pending.add(id(r))
             elif r.need_dx:
                 dst, acc = self._grad_target(r.x)
-                if r.pw_b:
+                if r.s2m_b:
+                    ops.append(_op(L.OP_CONV_BWD_DATA_S2M, p=[dy, r.wb, dst],
+                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
+                elif r.pw_b:
                     ops.append(_op(L.OP_CONV_PW_BWD_DATA, p=[dy, None, r.wb, dst],
                                    i=[r.cout, 0, lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
                 elif r.wino_b:
