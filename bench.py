@@ -60,7 +60,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD):
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
@@ -200,14 +200,14 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "traffic_note": "HBM-side bytes per step over the same 62 launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                                              "profiles/r01_hbm_traffic.json, tools/hbm_traffic.py); algorithmic 8.41e9",
+                              "traffic_note": "HBM-side bytes per step over the same forward-convolution launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                                              "profiles/r01_hbm_traffic.json, tools/hbm_traffic.py); algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
                               "kernel": "forward convolutions: wino_kernel (22 3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
                                         "the algorithmic multiplies) + pw_gemm_kernel (1x1) + gather_gemm_kernel (stride-2, "
                                         "wide 1x1, head outputs) + stem_conv_kernel (first layer, VALU)",
                               "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
                               "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
-                              "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0), 3),
+                              "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0) + per_kind.get(L.OP_CONV_PW_FWD2, 0.0), 3),
                               "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
                               "launches_per_step": n_launch,
                               # north_star's target quantity: the whole Conv+BN+SiLU forward against the same peak.  Two

@@ -118,8 +118,8 @@ int64_t yh_conv_pw_bwd_weight_ws(int64_t M, int Cin, int Cout);
 /* Forward / backward-data of a pointwise (1x1, stride 1) convolution over M = B*H*W pixels as a register-direct MFMA
  * GEMM (no LDS in the loop).  Weights in the k-quad interleaved layout Wq[K/4][ldw][4] written by yh_pw_pack_multi
  * (`table`: DEVICE array of 48-byte records { const float *oihw; float *wq_fwd, *wq_bwd; int32 Cout, Cin, ldw_fwd,
- * ldw_bwd, koff_bwd, 0 }; either destination may be NULL; koff_bwd = first K row of this conv inside a stacked
- * backward matrix).  Channel counts feeding K must be multiples of 8.  yh_conv_pw_fwd: same contract as yh_conv_fwd
+ * ldw_bwd, koff_bwd, noff_fwd }; either destination may be NULL; koff_bwd / noff_fwd = first K row / first column of this
+ * conv inside a stacked backward / forward matrix; the forward pack writes only its own columns: allocate wq_fwd zeroed).  Channel counts feeding K must be multiples of 8.  yh_conv_pw_fwd: same contract as yh_conv_fwd
  * (k = 1), bn_partials [yh_conv_pw_blocks(M, Cout)][2][Cout].  yh_conv_pw_bwd_data: dx (+)= dy1 W1^T (+ dy2 W2^T when
  * dy2 != NULL: the C3 sibling pair, K = cout1 + cout2 stacked in wq).
  * replaces: nn.Conv2d(k=1) forward and input gradient, train.py:236-240, 282-296, 402-418, 913. */
@@ -127,6 +127,13 @@ int yh_pw_pack_multi(const void *table, int n, void *stream);
 int yh_conv_pw_blocks(int64_t M, int Cout);
 int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const float *bias, float *y, int ldy, float *bn_partials,
                    int64_t M, int Cin, int Cout, void *stream);
+/* Two sibling pointwise convolutions that read the same x (C3's conv1 / conv2, train.py:282-293) as ONE GEMM with
+ * N = cout1 + cout2: wq holds both weight matrices side by side (pack records with noff = 0 and noff = cout1 into a
+ * zero-initialised buffer), each output tensor keeps its own ld, bias and BatchNorm partials
+ * [yh_conv_pw_blocks(M, cout1 + cout2)][2][cout_i]. */
+int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw, const float *bias1, float *y1, int ldy1,
+                    float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2, int cout2,
+                    int64_t M, int Cin, void *stream);
 int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw, float *dx,
                         int lddx, int64_t M, int Cin, int accumulate, void *stream);
 /* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction
@@ -275,7 +282,7 @@ enum {
     YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
     YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT,
     YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA,
-    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M
+    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M, YH_OP_CONV_PW_FWD2
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side

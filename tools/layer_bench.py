@@ -55,7 +55,7 @@ def main():
 
     fa, fn = plan.fwd_ops
     ba, bn = plan.bwd_ops
-    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD})
+    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD})
     DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA, L.OP_CONV_BWD_DATA_S2M}
     tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT})
     other_f = time_ops(fa, fn, {L.OP_BN_SILU_FWD, L.OP_BN_FINALIZE, L.OP_PACK_WEIGHTS, L.OP_MAXPOOL5_FWD})
@@ -63,6 +63,8 @@ def main():
 
     def desc(o):
         i = o.i
+        if o.kind == L.OP_CONV_PW_FWD2:       # two sibling convs in one launch: listed as one conv with N = cout1 + cout2
+            return (i[3], i[4], i[5], i[6], i[7] + i[9], 1, 1)
         if o.kind == L.OP_CONV_PW_BWD_DATA:
             return (i[5], i[6], i[7], i[8], i[0], 1, 1)
         if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD, L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_DATA_S2M):

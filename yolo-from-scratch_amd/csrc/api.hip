@@ -91,6 +91,10 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_BWD_DATA_S2M:       /* same argument slots as YH_OP_CONV_BWD_DATA */
             return yh_conv_bwd_data_s2m((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4], i[5],
                                         i[6], i[7], i[10], st);
+        case YH_OP_CONV_PW_FWD2:            /* p: x, wq, bias1, y1, part1, bias2, y2, part2;  i: ldx, ldw, ldy1, B, H, W, Cin, cout1, ldy2, cout2 */
+            return yh_conv_pw_fwd2((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
+                                   (float *)p[4], i[7], (const float *)p[5], (float *)p[6], i[8], (float *)p[7], i[9],
+                                   (int64_t)i[3] * i[4] * i[5], i[6], st);
         case YH_OP_PW_PACK_MULTI:
             return yh_pw_pack_multi(p[0], i[0], st);
         case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */

@@ -234,10 +234,10 @@ extern "C" int yh_conv_pw_bwd_weight(const float *x, int ldx, const float *dy, i
 namespace {
 
 struct PwG {
-    const float *in, *in2, *Wq, *bias;
-    float *out, *stats;
-    int ldi, ldw, ldo;
-    int M, K, K1, N;            // K1: channels taken from `in` (the rest, K - K1, from `in2`)
+    const float *in, *in2, *Wq, *bias, *bias2;
+    float *out, *stats, *out2, *stats2;     // out2 != NULL: columns [N1, N) go to a second tensor (sibling convolutions that
+    int ldi, ldw, ldo, ldo2;                // share their input: one read of x, one GEMM with N = N1 + N2)
+    int M, K, K1, N, N1;        // K1: channels taken from `in` (the rest, K - K1, from `in2`); N1 = N when out2 == NULL
     int accumulate;
     unsigned in_bytes, in2_bytes;
 };
@@ -311,8 +311,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 32 + lr;
-        const bool nok = n < g.N;
-        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        const bool nok = n < g.N, second = n >= g.N1;
+        const int nl = second ? n - g.N1 : n;                       // column inside its own tensor
+        const float *bp = second ? g.bias2 : g.bias;
+        const float bias = (bp && nok) ? bp[nl] : 0.f;
+        float *const ob = (second ? g.out2 : g.out) + nl;
+        const int ldo = second ? g.ldo2 : g.ldo;
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
             for (int r = 0; r < 16; ++r) {
                 const int p = p0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (nok && p < g.M) {
-                    float *o = g.out + (size_t)p * g.ldo + n;
+                    float *o = ob + (size_t)p * ldo;
                     float v = acc[i][j][r] + bias;
                     if (g.accumulate) v += *o;
                     *o = v;
@@ -341,8 +345,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
         if (t < 32 * NT && n0 + t < g.N) {
             float a0 = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
             float a1 = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
-            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = a0;
-            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = a1;
+            const int n = n0 + t;
+            float *sp = n >= g.N1 ? g.stats2 : g.stats;              // each tensor has its own [blocks][2][C] partials
+            const int C = n >= g.N1 ? g.N - g.N1 : g.N1, nl = n >= g.N1 ? n - g.N1 : n;
+            sp[((size_t)blockIdx.x * 2 + 0) * C + nl] = a0;
+            sp[((size_t)blockIdx.x * 2 + 1) * C + nl] = a1;
         }
     }
 }
@@ -350,17 +357,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
 struct PwPackDesc {
     const float *w;             // [Cout][Cin] (OIHW, 1x1)
     float *wf, *wb;             // forward: Wq[Cin/4][ldwf][4]; backward-data: Wq[(koff + Cout)/4 rows...][ldwb][4]
-    int Cout, Cin, ldwf, ldwb, koff, pad;
+    int Cout, Cin, ldwf, ldwb, koff, noff;   // noff: first column of this conv inside a stacked forward matrix
 };
 
 // forward  Wq_f[ci >> 2][co][ci & 3] = w[co][ci];   backward  Wq_b[(koff + co) >> 2][ci][(koff + co) & 3] = w[co][ci]
 __global__ void pw_pack_multi_kernel(const PwPackDesc *__restrict__ tab) {
     const PwPackDesc d = tab[blockIdx.y];
-    const int nf = d.wf ? d.Cin * d.ldwf : 0, nb = d.wb ? d.Cout * d.ldwb : 0;
+    // forward: only this conv's own columns are written (padding columns keep the zeros of the allocation)
+    const int nf = d.wf ? d.Cin * d.Cout : 0, nb = d.wb ? d.Cout * d.ldwb : 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
         if (i < nf) {
-            int n = i % d.ldwf, k = i / d.ldwf;
-            d.wf[((size_t)(k >> 2) * d.ldwf + n) * 4 + (k & 3)] = n < d.Cout ? d.w[(size_t)n * d.Cin + k] : 0.f;
+            int n = i % d.Cout, k = i / d.Cout;
+            d.wf[((size_t)(k >> 2) * d.ldwf + d.noff + n) * 4 + (k & 3)] = d.w[(size_t)n * d.Cin + k];
         } else {
             int j = i - nf;
             int n = j % d.ldwb, k = j / d.ldwb, kk = d.koff + k;
@@ -374,6 +382,7 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
                    (!g.in2 || (((uintptr_t)g.in2) & 15) == 0) && g.ldw >= g.N && g.M > 0,
                "conv_pw: channels must be multiples of 8, operands 16-byte addressable");
     YH_REQUIRE(((int64_t)(g.M - 1) * g.ldi + g.K) * 4 < (1ll << 31), "conv_pw: input view must span less than 2 GiB");
+    if (!g.out2) g.N1 = g.N;
     g.in_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + g.K1) * 4);
     g.in2_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + (g.K - g.K1)) * 4);
     const int NT = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
@@ -409,6 +418,17 @@ extern "C" int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw,
     PwG g{};
     g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
+    return launch_pw_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw, const float *bias1, float *y1, int ldy1,
+                               float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2,
+                               int cout2, int64_t M, int Cin, void *stream) {
+    YH_REQUIRE(x && wq && y1 && y2 && M > 0 && M < (1ll << 30) && ldx >= Cin && ldy1 >= cout1 && ldy2 >= cout2 && cout1 > 0 && cout2 > 0 &&
+                   (!bn_partials1) == (!bn_partials2), "conv_pw_fwd2: bad argument");
+    PwG g{};
+    g.in = x; g.Wq = wq; g.bias = bias1; g.bias2 = bias2; g.out = y1; g.out2 = y2; g.stats = bn_partials1; g.stats2 = bn_partials2;
+    g.ldi = ldx; g.ldw = ldw; g.ldo = ldy1; g.ldo2 = ldy2; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = cout1 + cout2; g.N1 = cout1;
     return launch_pw_gemm(g, (hipStream_t)stream);
 }
 

@@ -102,6 +102,8 @@ class ConvRec:
     pw_f: bool = False      # forward on the pointwise GEMM kernel
     stem_f: bool = False    # forward on the direct VALU kernel of the first layer
     s2m_b: bool = False     # stride-2 backward-data with the column parities merged into the channel axis
+    fwd2: bool = False      # forward fused with the sibling pointwise conv (one GEMM, N = cout1 + cout2)
+    nblk: int = 0           # BatchNorm partial-sum rows written by the forward kernel
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
@@ -237,15 +239,28 @@ class Plan:
                 if len(grp) == 2 and grp[0].cout == grp[1].cout and (self.need_input_grad or grp[0].x.buf is not self.input):
                     grp[0].pair, grp[1].pair = grp[1], grp[0]
                     grp[0].pair_first = True
-        for r in self.recs:
+                    a = grp[0]           # forward fusion (one GEMM, N = cout1 + cout2): decided here so the lowering below
+                    a.fwd2 = grp[1].fwd2 = (  # can order the fused launch before a side-lane fork
+                        os.environ.get("YH_PAIR_FWD", "1") != "0" and os.environ.get("YH_PWG", "1") != "0"
+                        and a.cin == a.weight.shape[1] and a.x.ld % 4 == 0 and a.cin % 8 == 0
+                        and not (a.cin >= 256 and a.cout >= 256))
+        deferred_fork = False
+        for ri, r in enumerate(self.recs):
             if isinstance(r, SyncRec):
-                fwd.append(_op(L.OP_FORK if r.kind == "fork" else L.OP_JOIN))
+                nxt = self.recs[ri + 1] if ri + 1 < len(self.recs) else None
+                if r.kind == "fork" and isinstance(nxt, ConvRec) and nxt.fwd2 and nxt.pair_first and nxt.lane == 1:
+                    deferred_fork = True     # the fused sibling conv runs on the main lane; fork right after it (below)
+                else:
+                    fwd.append(_op(L.OP_FORK if r.kind == "fork" else L.OP_JOIN))
                 continue
             ln = r.lane
             if isinstance(r, ConvRec):
                 kk = r.k * r.k
-                r.ldwf, r.ldwb = _rup4(r.cout), _rup4(r.cin)
-                r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
+                fused_second = r.fwd2 and r.pair is not None and not r.pair_first and r.wf is not None   # shares its sibling's matrix
+                r.ldwb = _rup4(r.cin)
+                if not fused_second:
+                    r.ldwf = _rup4(r.cout)
+                    r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
                 if not self.training:
                     # eval: one fused kernel per conv -- conv + folded-BN bias + SiLU (+residual) (+x2 upsample)
                     fbias = torch.empty(r.cout, **f32)
@@ -293,10 +308,18 @@ class Plan:
                     s2m_packs.append(_op(L.OP_PACK_WEIGHTS_S2M, p=[r.weight, r.wb], i=[r.cout, r.cin, r.ldwb]))
                 else:
                     r.wb = torch.empty((16 if r.wino_b else kk) * r.cout * r.ldwb, **f32) if r.need_dx else None
+                second = r.pair is not None and not r.pair_first
+                assert not r.fwd2 or r.pw_f                  # same eligibility rule (decided at pair detection)
+                if r.pw_f:                                   # the pointwise pack writes only the conv's own columns
+                    if r.fwd2 and not second:
+                        r.ldwf = r.pair.ldwf = _rup4(r.cout + r.pair.cout)
+                        r.wf = r.pair.wf = torch.zeros(r.cin * r.ldwf, **f32)
+                    elif not r.fwd2:
+                        r.wf = torch.zeros(r.cin * r.ldwf, **f32)
                 if r.pw_f or r.pw_b:
-                    koff = r.pair.cout if (r.pair is not None and not r.pair_first) else 0
+                    koff = r.pair.cout if second else 0
                     pwpacks.append((r.weight.data_ptr(), r.wf.data_ptr() if r.pw_f else 0, r.wb.data_ptr() if r.pw_b else 0,
-                                    r.cout, r.cin, r.ldwf, r.ldwb, koff, 0))
+                                    r.cout, r.cin, r.ldwf, r.ldwb, koff, r.pair.cout if (second and r.fwd2) else 0))
                 if r.wino_f:
                     r.wf = torch.empty(16 * r.cin * r.ldwf, **f32)
                     winos.append((r.weight.data_ptr(), r.wf.data_ptr(), r.cout, r.weight.shape[1], r.ldwf, 0))
@@ -307,24 +330,41 @@ class Plan:
                 if gen_f or gen_b:
                     packs.append((r.weight.data_ptr(), r.wf.data_ptr() if gen_f else 0, r.wb.data_ptr() if gen_b else 0,
                                   r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, r.ldwb))
-                r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **f32) if r.bn is not None else None
-                if r.bn is not None:
-                    r.coef = torch.empty(4 * r.cout, **f32)
-                    ytarget, ldy = r.y, r.cout
-                else:
-                    ytarget, ldy = None, r.out.ld
-                nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
-                    lib.yh_conv_pw_blocks(r.x.B * r.x.H * r.x.W, r.cout) if r.pw_f else \
-                    lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
-                    lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                 M = r.x.B * r.Ho * r.Wo
-                if r.bn is not None:
-                    nb_bwd = lib.yh_bn_bwd_blocks(M, r.cout)
-                    r.part = torch.empty(max(nblk, nb_bwd) * 2 * r.cout, **f32)
-                fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else (L.OP_CONV_STEM_FWD if r.stem_f else L.OP_CONV_FWD)),
-                               p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
-                                  r.part if r.bn is not None else None],
-                               i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
+
+                def alloc_out(c: ConvRec, nblk: int):        # raw conv output, BN coefficients and partial-sum scratch
+                    c.nblk = nblk
+                    if c.bn is not None and c.y is None:
+                        c.y = torch.empty(c.x.B, c.Ho, c.Wo, c.cout, **f32)
+                        c.coef = torch.empty(4 * c.cout, **f32)
+                        c.part = torch.empty(max(nblk, lib.yh_bn_bwd_blocks(M, c.cout)) * 2 * c.cout, **f32)
+
+                if r.fwd2:
+                    if r.pair_first:      # both siblings in one launch, at the first one's position in the list
+                        nblk = lib.yh_conv_pw_blocks(M, r.cout + r.pair.cout)
+                        alloc_out(r, nblk)
+                        alloc_out(r.pair, nblk)
+                        q = r.pair
+                        # on the main lane whatever lane the record was traced on: both siblings' BN passes depend on it
+                        fwd.append(_op(L.OP_CONV_PW_FWD2, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part, q.bias, q.y, q.part],
+                                       i=[r.x.ld, r.ldwf, r.cout, r.x.B, r.x.H, r.x.W, r.cin, r.cout, q.cout, q.cout], lane=0))
+                        if deferred_fork:
+                            fwd.append(_op(L.OP_FORK))
+                            deferred_fork = False
+                        elif ln == 1 or q.lane == 1:
+                            raise NotImplementedError("fused sibling convolution traced on the side lane without a preceding fork")
+                else:
+                    nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
+                        lib.yh_conv_pw_blocks(M, r.cout) if r.pw_f else \
+                        lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
+                        lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
+                    alloc_out(r, nblk)
+                    ytarget, ldy = (r.y, r.cout) if r.bn is not None else (None, r.out.ld)
+                    fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else (L.OP_CONV_STEM_FWD if r.stem_f else L.OP_CONV_FWD)),
+                                   p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
+                                      r.part if r.bn is not None else None],
+                                   i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
+                nblk = r.nblk
                 if r.bn is not None:
                     track = r.bn.track_running_stats and r.bn.running_mean is not None
                     mom = r.bn.momentum if r.bn.momentum is not None else 0.1
