@@ -62,6 +62,14 @@ int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s);
 int yh_conv_fwd_fused(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res, int ldr,
                       float *y, int ldy, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int act_silu,
                       int upsample, void *stream);
+/* Small-M (batch-1 inference) form of yh_conv_fwd_fused: when a 3x3 layer would launch fewer than 256 workgroups its
+ * taps are split over four partial GEMMs in ONE launch (workspace slabs, ws_floats >= yh_conv_fwd_fused_ws(...)), then
+ * a finish kernel adds the slabs in fixed order and applies bias / SiLU / residual / upsample.  With ws == NULL or a layer
+ * the heuristic leaves alone (yh_conv_fwd_fused_ws == 0) it is yh_conv_fwd_fused. */
+int yh_conv_fwd_fused_splitk(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res, int ldr,
+                             float *y, int ldy, float *ws, int64_t ws_floats, int B, int Hi, int Wi, int Cin, int Cout, int k,
+                             int s, int act_silu, int upsample, void *stream);
+int64_t yh_conv_fwd_fused_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s);
 /* Fold eval-mode BatchNorm into packed forward weights for n_layers convolutions in one launch.  `table` is a
  * DEVICE array of 88-byte records { const float *oihw, *bias_in, *gamma, *beta, *running_mean, *running_var;
  * float *wf, *bias_out; int32 Cout, Cin, k*k, cin_pad, ldwf; float eps } (gamma == NULL: plain pack + bias copy). */

@@ -332,3 +332,43 @@ def test_stride2_backward_data_merged_parities(B, H, W, Cin, Cout):
     L.check(lib.yh_conv_bwd_data_s2m(dyd.data_ptr(), Cout, wbm.data_ptr(), ldw, dx3.data_ptr(), Cin, B, H, W, Cin, Cout, 0, st))
     assert rel_err(dx3, dx2) < 1e-5
     assert lib.yh_conv_bwd_data_s2m(dyd.data_ptr(), Cout, wbm.data_ptr(), ldw, dx3.data_ptr(), Cin + 4, B, H, W, Cin, Cout, 0, st) != 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s,res,up", [(1, 20, 20, 256, 256, 1, True, False), (1, 40, 40, 64, 64, 1, False, True),
+                                                      (1, 21, 13, 32, 48, 2, False, False), (2, 16, 16, 128, 128, 1, False, False)])
+def test_small_m_tap_split_inference_conv(B, H, W, Cin, Cout, s, res, up):
+    """yh_conv_fwd_fused_splitk (taps dealt to four partial GEMMs + fixed-order finish) = yh_conv_fwd_fused = fp64 torch,
+    with residual / upsample / odd sizes; it is a plain call when the layer is large or no workspace is given."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(H + Cin + s)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout)
+    ref = F.silu(F.conv2d(x.double(), w.double(), bias.double(), s, 1))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = torch.randn(B, Cout, Ho, Wo) if res else None
+    if res:
+        ref = ref + r.double()
+    if up:
+        ref = F.interpolate(ref, scale_factor=2, mode="nearest")
+    st = torch.cuda.current_stream().cuda_stream
+    wf = torch.empty(9 * Cin * rup4(Cout), device="cuda")
+    L.check(lib.yh_pack_weights(w.cuda().data_ptr(), wf.data_ptr(), None, Cout, Cin, 3, Cin, rup4(Cout), rup4(Cin), st))
+    xd, bd = nhwc(x), bias.cuda()
+    rd = nhwc(r) if res else None
+    f = 2 if up else 1
+    nws = lib.yh_conv_fwd_fused_ws(B, H, W, Cin, Cout, 3, s)
+    assert nws > 0
+    ws = torch.full((nws,), 1e30, device="cuda")
+    y1 = torch.empty(B, Ho * f, Wo * f, Cout, device="cuda")
+    y2 = torch.empty_like(y1)
+    args = (xd.data_ptr(), Cin, wf.data_ptr(), rup4(Cout), bd.data_ptr(), rd.data_ptr() if res else None, Cout if res else 0)
+    L.check(lib.yh_conv_fwd_fused_splitk(*args, y1.data_ptr(), Cout, ws.data_ptr(), nws, B, H, W, Cin, Cout, 3, s, 1, int(up), st))
+    L.check(lib.yh_conv_fwd_fused(*args, y2.data_ptr(), Cout, B, H, W, Cin, Cout, 3, s, 1, int(up), st))
+    assert rel_err(y1.permute(0, 3, 1, 2), ref) < 1e-5 and rel_err(y1, y2) < 1e-5
+    y3 = torch.empty_like(y1)
+    L.check(lib.yh_conv_fwd_fused_splitk(*args, y3.data_ptr(), Cout, None, 0, B, H, W, Cin, Cout, 3, s, 1, int(up), st))
+    assert torch.equal(y3, y2)
+    assert lib.yh_conv_fwd_fused_splitk(*args, y3.data_ptr(), Cout, ws.data_ptr(), nws - 1, B, H, W, Cin, Cout, 3, s, 1, int(up), st) != 0
+    assert lib.yh_conv_fwd_fused_ws(64, 160, 160, 32, 32, 3, 1) == 0 and lib.yh_conv_fwd_fused_ws(1, 80, 80, 64, 64, 1, 1) == 0

@@ -55,6 +55,9 @@ _SIGS = {
     "yh_conv_wino_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32]),
+    "yh_conv_fwd_fused_splitk": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                       c_fp]),
+    "yh_conv_fwd_fused_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data_s2m": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_weights_s2m": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "yh_conv_stem_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),

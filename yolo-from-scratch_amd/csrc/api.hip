@@ -110,10 +110,10 @@ static int run_one(const yh_op &o, void *st) {
             return yh_pack_weights_multi(p[0], i[0], st);
         case YH_OP_PACK_FOLD_MULTI:
             return yh_pack_fold_multi(p[0], i[0], st);
-        case YH_OP_CONV_FWD_FUSED:
-            return yh_conv_fwd_fused((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
-                                     (const float *)p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9],
-                                     i[10], i[11], i[12], st);
+        case YH_OP_CONV_FWD_FUSED:          /* p[5] / l[0]: optional split-K workspace (small-M layers) */
+            return yh_conv_fwd_fused_splitk((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
+                                            (const float *)p[3], i[2], (float *)p[4], i[3], (float *)p[5], o.l[0], i[4], i[5], i[6],
+                                            i[7], i[8], i[9], i[10], i[11], i[12], st);
         default:
             yh_set_error("yh_run: unknown op kind %d", o.kind);
             return YH_E_BADARG;
@@ -141,13 +141,15 @@ static int side_ready() {
     }
     if (!g_overlap) return 0;
     if (!g_side) {
-        // the side lane carries work off the critical path (weight gradients, independent branches): lowest queue priority,
-        // so the caller's stream gets the CUs first (22.21 -> 22.12 ms/step; YH_SIDE_PRIORITY=none|high to compare)
+        // YH_SIDE_PRIORITY=low|high: experiment knob.  A low-priority side lane measured 22.21 -> 22.12 ms/step in training
+        // (noise level) but a captured hipGraph with mixed-priority nodes replays 2x slower (2.4 -> 4.8 ms at bs=1), so the
+        // default is an ordinary stream.
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = numerically greatest = lowest priority
         const char *pr = getenv("YH_SIDE_PRIORITY");
-        hipError_t e = (pr && pr[0] == 'n') ? hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking)
-                                             : hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, (pr && pr[0] == 'h') ? hi : lo);
+        hipError_t e = (pr && (pr[0] == 'l' || pr[0] == 'h'))
+                           ? hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, pr[0] == 'l' ? lo : hi)
+                           : hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
         if (e != hipSuccess ||
             hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) {

@@ -455,6 +455,102 @@ extern "C" int yh_conv_fwd_fused(const float *x, int ldx, const float *wf, int l
     return launch(g, (hipStream_t)stream);
 }
 
+// ---- small-M inference: split the 3x3 reduction over taps ---------------------------------------------------------
+// At batch 1 a 3x3 layer has few output tiles (7 x 4 workgroups for 256 -> 256 at 20x20) and a long K loop (72 chunks):
+// the layer's latency is one workgroup's K loop.  The taps are dealt to up to four "classes" of the multi-class launch
+// (the mechanism of the stride-2 backward-data), each writing its partial sums to a workspace slab; a small finish
+// kernel adds the slabs in fixed order and applies bias / SiLU / residual / x2 upsample.
+namespace {
+__global__ void splitk_finish_kernel(const float *__restrict__ ws, int ncls, int64_t M, int N, int ldws, const float *__restrict__ bias,
+                                     const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo, int act, int up2,
+                                     int Ho, int Wo) {
+    const int nq = ldws >> 2;
+    const int64_t total = M * nq;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / nq;
+        const int n = (int)(i - m * nq) << 2;
+        f32x4 v = *(const f32x4 *)(ws + m * ldws + n);
+        for (int c = 1; c < ncls; ++c) v += *(const f32x4 *)(ws + ((int64_t)c * M + m) * ldws + n);
+        int64_t opix = m;
+        if (up2) {
+            int64_t q = m / Wo;
+            int x = (int)(m - q * Wo);
+            int64_t b = q / Ho;
+            int y = (int)(q - b * Ho);
+            opix = (b * (2 * Ho) + 2 * y) * (int64_t)(2 * Wo) + 2 * x;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= N) break;
+            float t = v[e] + (bias ? bias[n + e] : 0.f);
+            if (act) t = t * yh_sigmoid(t);
+            if (res) t += res[m * ldr + n + e];
+            float *o = out + opix * ldo + n + e;
+            o[0] = t;
+            if (up2) {
+                const int64_t rs = (int64_t)(2 * Wo) * ldo;
+                o[ldo] = t; o[rs] = t; o[rs + ldo] = t;
+            }
+        }
+    }
+}
+
+int splitk_classes(int B, int Hi, int Wi, int Cout, int k, int s) {
+    if (k != 3) return 1;
+    const int Ho = (Hi + 2 - 3) / s + 1, Wo = (Wi + 2 - 3) / s + 1;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const int64_t tiles = ((M + 63) / 64) * ((Cout + 63) / 64);     // roughly the workgroups of the unsplit launch
+    return tiles < 256 ? 4 : 1;
+}
+}  // namespace
+
+extern "C" int64_t yh_conv_fwd_fused_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
+    (void)Cin;
+    const int nc = splitk_classes(B, Hi, Wi, Cout, k, s);
+    if (nc == 1) return 0;
+    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
+    return (int64_t)nc * B * Ho * Wo * ((Cout + 3) / 4 * 4);
+}
+
+extern "C" int yh_conv_fwd_fused_splitk(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res,
+                                        int ldr, float *y, int ldy, float *ws, int64_t ws_floats, int B, int Hi, int Wi, int Cin,
+                                        int Cout, int k, int s, int act_silu, int upsample, void *stream) {
+    const int nc = splitk_classes(B, Hi, Wi, Cout, k, s);
+    if (nc == 1 || !ws) return yh_conv_fwd_fused(x, ldx, wf, ldwf, bias, res, ldr, y, ldy, B, Hi, Wi, Cin, Cout, k, s, act_silu, upsample, stream);
+    YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_fwd_fused_splitk: bad argument");
+    YH_REQUIRE(ldx >= Cin && ldy >= Cout && (!res || ldr >= Cout), "conv_fwd_fused_splitk: ld smaller than channel count");
+    YH_REQUIRE(ws_floats >= yh_conv_fwd_fused_ws(B, Hi, Wi, Cin, Cout, k, s), "conv_fwd_fused_splitk: workspace too small");
+    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1, ldws = (Cout + 3) / 4 * 4;
+    const int64_t M = (int64_t)B * Ho * Wo;
+    static const int first[5] = {0, 3, 5, 7, 9};       // taps {0,1,2} {3,4} {5,6} {7,8}
+    GatherGemmSet gs{};
+    for (int c = 0; c < nc; ++c) {
+        GatherGemm g{};
+        g.in = x; g.w = wf; g.bias = nullptr; g.out = ws + (size_t)c * M * ldws; g.stats = nullptr;
+        g.Hi = Hi; g.Wi = Wi; g.ldi = ldx; g.Cin = Cin; g.ldw = ldwf;
+        g.Ho_f = Ho; g.Wo_f = Wo; g.ldo = ldws; g.N = Cout;
+        g.B = B; g.Yo = Ho; g.Xo = Wo; g.M = (int)M;
+        g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
+        g.accumulate = 0; g.dense = 1;
+        int nt = 0;
+        for (int t = first[c]; t < first[c + 1]; ++t) {
+            g.tap_dy[nt] = t / 3 - p; g.tap_dx[nt] = t % 3 - p; g.tap_w[nt] = t;
+            ++nt;
+        }
+        g.nTaps = nt; g.Ktot = nt * Cin;
+        gs.c[c] = g;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_set<4>(gs, st);
+    if (rc) return rc;
+    const int64_t total = M * (ldws / 4);
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, st, ws, nc, M, Cout, ldws, bias, res, ldr, y,
+                       ldy, act_silu ? 1 : 0, upsample ? 1 : 0, Ho, Wo);
+    YH_CHECK_LAUNCH("splitk_finish");
+    return 0;
+}
+
 extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B,
                                 int Hi, int Wi, int Cin, int Cout, int k, int s, int accumulate, void *stream) {
     YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_bwd_data: unsupported k=%d s=%d", k, s);

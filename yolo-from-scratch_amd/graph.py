@@ -271,10 +271,15 @@ class Plan:
                                   bn.running_mean.data_ptr() if bn is not None else 0,
                                   bn.running_var.data_ptr() if bn is not None else 0, r.wf.data_ptr(), fbias.data_ptr(),
                                   r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, float(bn.eps) if bn is not None else 0.0))
+                    nws = int(lib.yh_conv_fwd_fused_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s)) \
+                        if os.environ.get("YH_SPLITK", "1") != "0" else 0
+                    sws = torch.empty(nws, **f32) if nws > 0 else None      # per layer: two lanes may run split layers at once
+                    if sws is not None:
+                        keep.append(sws)
                     fwd.append(_op(L.OP_CONV_FWD_FUSED,
-                                   p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()],
+                                   p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr(), sws],
                                    i=[r.x.ld, r.ldwf, r.residual.ld if r.residual else 0, r.out.ld, r.x.B, r.x.H, r.x.W,
-                                      r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], lane=ln))
+                                      r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], l=[nws], lane=ln))
                     continue
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
                 wino_ok = use_wino and r.k == 3 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.x.ld % 4 == 0
