@@ -232,11 +232,17 @@ __device__ __forceinline__ float silu_grad(float z) {
 __global__ void bn_silu_fwd_kernel(const float *__restrict__ y, int ldy, const float *__restrict__ coef,
                                    const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
                                    int64_t M, int C, int H, int W, int upsample) {
+    // (row, channel-quad) cursor advanced incrementally: the grid-stride index i = m * cq + c4 is never divided inside
+    // the loop (a 64-bit division per float4 cost more VALU time than the four sigmoids)
     const int cq = C >> 2;
-    const int64_t total = M * cq;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t m = i / cq;
-        int c = (int)(i - m * cq) << 2;
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t m = i0 / cq;
+    int c4 = (int)(i0 - m * cq);
+    const int64_t dm = stride / cq;
+    const int dc = (int)(stride - dm * cq);
+    for (; m < M; m += dm, c4 += dc) {
+        if (c4 >= cq) { c4 -= cq; if (++m >= M) break; }
+        const int c = c4 << 2;
         f32x4 v = *(const f32x4 *)(y + m * ldy + c);
         f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
         f32x4 a;
@@ -249,9 +255,9 @@ __global__ void bn_silu_fwd_kernel(const float *__restrict__ y, int ldy, const f
         if (!upsample) {
             *(f32x4 *)(out + m * ldo + c) = a;
         } else {
-            int64_t w = m % W, q = m / W;
-            int64_t h = q % H, b = q / H;
-            float *o = out + (((b * 2 * H + 2 * h) * 2 * W) + 2 * w) * ldo + c;
+            const unsigned mu32 = (unsigned)m, q = mu32 / (unsigned)W, w = mu32 - q * (unsigned)W;      // M < 2^31
+            const unsigned b = q / (unsigned)H, h = q - b * (unsigned)H;
+            float *o = out + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldo + c;
             *(f32x4 *)(o) = a;
             *(f32x4 *)(o + ldo) = a;
             *(f32x4 *)(o + (size_t)2 * W * ldo) = a;
@@ -263,9 +269,9 @@ __global__ void bn_silu_fwd_kernel(const float *__restrict__ y, int ldy, const f
 __device__ __forceinline__ f32x4 load_da(const float *__restrict__ da, int ldda, int64_t m, int c, int H, int W,
                                          int upsample) {
     if (!upsample) return *(const f32x4 *)(da + m * ldda + c);
-    int64_t w = m % W, q = m / W;
-    int64_t h = q % H, b = q / H;
-    const float *p = da + (((b * 2 * H + 2 * h) * 2 * W) + 2 * w) * ldda + c;
+    const unsigned mu32 = (unsigned)m, q = mu32 / (unsigned)W, w = mu32 - q * (unsigned)W;              // M < 2^31
+    const unsigned b = q / (unsigned)H, h = q - b * (unsigned)H;
+    const float *p = da + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldda + c;
     f32x4 a = *(const f32x4 *)p, b1 = *(const f32x4 *)(p + ldda);
     f32x4 c1 = *(const f32x4 *)(p + (size_t)2 * W * ldda), d1 = *(const f32x4 *)(p + (size_t)2 * W * ldda + ldda);
     return (a + b1) + (c1 + d1);
@@ -356,11 +362,15 @@ __global__ void bn_silu_bwd_apply_kernel(const float *__restrict__ da, int ldda,
                                          float *__restrict__ dres, int lddres, int res_acc, int64_t M, int C, int H,
                                          int W, int upsample) {
     const int cq = C >> 2;
-    const int64_t total = M * cq;
     const float inv_n = 1.0f / (float)M;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t m = i / cq;
-        int c = (int)(i - m * cq) << 2;
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t m = i0 / cq;                       // division-free cursor, see bn_silu_fwd_kernel
+    int c4 = (int)(i0 - m * cq);
+    const int64_t dm = stride / cq;
+    const int dc = (int)(stride - dm * cq);
+    for (; m < M; m += dm, c4 += dc) {
+        if (c4 >= cq) { c4 -= cq; if (++m >= M) break; }
+        const int c = c4 << 2;
         f32x4 yv = *(const f32x4 *)(y + m * ldy + c);
         f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
         f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
@@ -587,7 +597,7 @@ extern "C" int yh_bn_eval_coef(const float *gamma, const float *beta, const floa
 
 extern "C" int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
                               int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
-    YH_REQUIRE(y && coef && out && M > 0, "bn_silu_fwd: bad argument");
+    YH_REQUIRE(y && coef && out && M > 0 && M < (1ll << 31), "bn_silu_fwd: bad argument");
     YH_REQ_VEC4("bn_silu_fwd", C, ldy, ldo, residual ? ldr : 0);
     YH_REQUIRE(!upsample || (H > 0 && W > 0 && M % ((int64_t)H * W) == 0), "bn_silu_fwd: upsample needs H, W");
     hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
@@ -605,7 +615,7 @@ extern "C" int yh_bn_bwd_blocks(int64_t M, int C) {
 
 extern "C" int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef,
                                      float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
-    YH_REQUIRE(da && y && coef && partials && M > 0, "bn_silu_bwd_reduce: bad argument");
+    YH_REQUIRE(da && y && coef && partials && M > 0 && M < (1ll << 31), "bn_silu_bwd_reduce: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_reduce", C, ldda, ldy);
     YH_REQUIRE(C <= 1024, "bn_silu_bwd_reduce: C too large");
     int nblk = yh_bn_bwd_blocks(M, C);
@@ -621,7 +631,7 @@ extern "C" int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, i
                                     float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C,
                                     int H, int W, int upsample, void *stream) {
     (void)gamma;
-    YH_REQUIRE(da && y && coef && partials && dgamma && dbeta && dy && M > 0 && nblk > 0, "bn_silu_bwd_apply: bad argument");
+    YH_REQUIRE(da && y && coef && partials && dgamma && dbeta && dy && M > 0 && M < (1ll << 31) && nblk > 0, "bn_silu_bwd_apply: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_apply", C, ldda, ldy, lddy, dres ? lddres : 0);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
                        C);
