@@ -110,6 +110,17 @@ int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const flo
                      float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
 int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                           int W, int Cin, int Cout, int accumulate, void *stream);
+/* Backward-data kernels that ALSO produce the BatchNorm-backward sums of the layers whose activation gradient they
+ * finish writing (so the separate pass yh_bn_silu_bwd_reduce over dOut and y disappears for those layers).  bn_table:
+ * DEVICE array of n_bn (<= 8) 48-byte records { const float *y, *coef; float *partials; int32 col0, ncol, ldy, C, 0, 0 }:
+ * output columns [col0, col0 + ncol) of dx are the C = ncol channels of a producer whose pre-BN output is y (pixel
+ * stride ldy) and whose forward coefficients are coef (yh_bn_finalize); partials receives
+ * [rows][2][C] with rows = yh_conv_wino_blocks(B,H,W) resp. yh_conv_pw_blocks(M, Cin), to be handed to
+ * yh_bn_silu_bwd_apply as its (partials, nblk).  Only valid when this call writes the FINAL value of those columns. */
+int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H, int W,
+                             int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream);
+int yh_conv_pw_bwd_data_bn(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw, float *dx,
+                           int lddx, int64_t M, int Cin, int accumulate, const void *bn_table, int n_bn, void *stream);
 /* Backward-weight in the Winograd domain (Cin % 32 == 0, Cout % 32 == 0, even H, W): dw (OIHW) = the same sum as
  * yh_conv_bwd_weight for k = 3, s = 1, deterministic (fixed-order reduction of per-workgroup [9][Cin][Cout] slabs
  * through ws, ws_floats >= yh_conv_wino_bwd_weight_ws(...)). */
@@ -290,7 +301,7 @@ enum {
     YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
     YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT,
     YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA,
-    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M, YH_OP_CONV_PW_FWD2
+    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M, YH_OP_CONV_PW_FWD2, YH_OP_NOP
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side

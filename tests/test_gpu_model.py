@@ -343,3 +343,24 @@ def test_full_size_step_properties(monkeypatch):
             assert float((ga - gc).abs().max()) <= 5e-3 * scale, n
             checked += 1
     assert checked > 150
+
+
+def test_bn_backward_sums_in_dgrad_epilogue_match_the_reduce_pass(monkeypatch):
+    """YH_BN_EPI=1 (off by default: slower) moves the BatchNorm-backward sums into the epilogue of the backward-data GEMM that
+    finishes a layer's activation gradient (yh_conv_wino_bwd_data_bn / yh_conv_pw_bwd_data_bn): same gradients as the
+    separate reduce pass to fp32 summation-order noise."""
+    y = api()
+    x = torch.rand(2, 3, 320, 320, generator=torch.Generator().manual_seed(41)).cuda()
+    tg = [t.cuda() for t in y.synthetic_targets(2, 1, 320, 8, 42)]
+    res = []
+    for epi in ("0", "1"):
+        monkeypatch.setenv("YH_BN_EPI", epi)
+        torch.manual_seed(0)
+        m = y.YOLO(num_classes=1, img_size=320).cuda()
+        tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
+        loss = tr.step(x, tg)[:4].cpu().clone()
+        res.append((loss, tr.flat_g.clone(), getattr(m._plan_for(x), "bn_epilogue_layers", 0)))
+    assert res[0][2] == 0 and res[1][2] >= 30            # most C3-internal layers are covered
+    assert torch.equal(res[0][0], res[1][0])              # the forward is untouched
+    d = (res[0][1] - res[1][1]).abs().max().item()
+    assert d <= 2e-4 * res[0][1].abs().max().item()

@@ -29,7 +29,7 @@ class YhOp(C.Structure):
  OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI, OP_PACK_FOLD_MULTI,
  OP_CONV_FWD_FUSED, OP_CONV_BWD_DATA_PAIR, OP_FORK, OP_JOIN, OP_WINO_WEIGHTS_MULTI, OP_CONV_WINO_FWD,
  OP_CONV_WINO_BWD_DATA, OP_CONV_WINO_BWD_WEIGHT, OP_CONV_PW_BWD_WEIGHT, OP_PW_PACK_MULTI, OP_CONV_PW_FWD,
- OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M, OP_CONV_PW_FWD2) = range(1, 35)
+ OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M, OP_CONV_PW_FWD2, OP_NOP) = range(1, 36)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -69,6 +69,8 @@ _SIGS = {
     "yh_conv_pw_bwd_data": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i64, i32, i32, c_fp]),
     "yh_conv_pw_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i64, i32, i32, c_fp]),
     "yh_conv_pw_bwd_weight_ws": (i64, [i64, i32, i32]),
+    "yh_conv_wino_bwd_data_bn": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i32, c_fp]),
+    "yh_conv_pw_bwd_data_bn": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i64, i32, i32, c_fp, i32, c_fp]),
     "yh_conv_wino_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_data_pair": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),

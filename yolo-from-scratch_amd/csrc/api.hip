@@ -74,9 +74,9 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_WINO_FWD:
             return yh_conv_wino_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3],
                                     i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], st);
-        case YH_OP_CONV_WINO_BWD_DATA:
-            return yh_conv_wino_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
-                                         i[5], i[6], i[7], i[8], st);
+        case YH_OP_CONV_WINO_BWD_DATA:      /* p[3] / i[9]: optional BatchNorm-backward table */
+            return yh_conv_wino_bwd_data_bn((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
+                                            i[5], i[6], i[7], i[8], p[3], i[9], st);
         case YH_OP_CONV_WINO_BWD_WEIGHT:
             return yh_conv_wino_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
                                            o.l[0], i[2], i[3], i[4], i[5], i[7], st);
@@ -100,9 +100,11 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */
             return yh_conv_pw_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
                                   (float *)p[4], (int64_t)i[3] * i[4] * i[5], i[6], i[7], st);
-        case YH_OP_CONV_PW_BWD_DATA:        /* p: dy1, dy2 | NULL, wq, dx;  i: cout1, cout2, lddy, ldw, lddx, B, H, W, Cin, accumulate */
-            return yh_conv_pw_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
-                                       (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], st);
+        case YH_OP_CONV_PW_BWD_DATA:        /* p: dy1, dy2 | NULL, wq, dx, bn table | NULL;  i: cout1, cout2, lddy, ldw, lddx, B, H, W, Cin, accumulate, n_bn */
+            return yh_conv_pw_bwd_data_bn((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
+                                          (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], p[4], i[10], st);
+        case YH_OP_NOP:
+            return 0;
         case YH_OP_CONV_BWD_DATA_PAIR:
             return yh_conv_bwd_data_pair((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
                                          (float *)p[3], i[4], i[5], i[6], i[7], i[8], i[9], st);

@@ -240,6 +240,8 @@ struct PwG {
     int M, K, K1, N, N1;        // K1: channels taken from `in` (the rest, K - K1, from `in2`); N1 = N when out2 == NULL
     int accumulate;
     unsigned in_bytes, in2_bytes;
+    const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns (common.h)
+    int bn_n;
 };
 
 template <int TM, int NT>
@@ -318,6 +320,17 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
         float *const ob = (second ? g.out2 : g.out) + nl;
         const int ldo = second ? g.ldo2 : g.ldo;
         float s = 0.f, q = 0.f;
+        const float *ey = nullptr;               // producer that owns this column (BatchNorm-backward sums, see YhBnBwdEntry)
+        int eldy = 0;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
+        for (int e = 0; e < g.bn_n; ++e) {
+            const YhBnBwdEntry en = g.bn_tab[e];
+            if (nok && n >= en.col0 && n < en.col0 + en.ncol) {
+                const int cl = n - en.col0;
+                eldy = en.ldy; ey = en.y + cl;
+                esc = en.coef[cl]; esh = en.coef[en.C + cl]; emu = en.coef[2 * en.C + cl]; eis = en.coef[3 * en.C + cl];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -328,14 +341,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
                     float v = acc[i][j][r] + bias;
                     if (g.accumulate) v += *o;
                     *o = v;
-                    s += v;
-                    q += v * v;
+                    if (ey) {
+                        yh_bn_bwd_accum(v, ey[(size_t)p * eldy], esc, esh, emu, eis, s, q);
+                    } else {
+                        s += v;
+                        q += v * v;
+                    }
                 }
             }
         csum[j] = s;
         csq[j] = q;
     }
-    if (g.stats) {
+    if (g.stats || g.bn_n) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
@@ -346,6 +363,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
             float a0 = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
             float a1 = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
             const int n = n0 + t;
+            if (!g.stats) {                      // BatchNorm-backward sums: into the owning producer's partials
+                for (int e = 0; e < g.bn_n; ++e) {
+                    const YhBnBwdEntry en = g.bn_tab[e];
+                    if (n >= en.col0 && n < en.col0 + en.ncol) {
+                        en.part[((size_t)blockIdx.x * 2 + 0) * en.C + n - en.col0] = a0;
+                        en.part[((size_t)blockIdx.x * 2 + 1) * en.C + n - en.col0] = a1;
+                    }
+                }
+                return;
+            }
             float *sp = n >= g.N1 ? g.stats2 : g.stats;              // each tensor has its own [blocks][2][C] partials
             const int C = n >= g.N1 ? g.N - g.N1 : g.N1, nl = n >= g.N1 ? n - g.N1 : n;
             sp[((size_t)blockIdx.x * 2 + 0) * C + nl] = a0;
@@ -432,11 +459,23 @@ extern "C" int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw
     return launch_pw_gemm(g, (hipStream_t)stream);
 }
 
+extern "C" int yh_conv_pw_bwd_data_bn(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
+                                      float *dx, int lddx, int64_t M, int Cin, int accumulate, const void *bn_table, int n_bn,
+                                      void *stream);
+
 extern "C" int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
                                    float *dx, int lddx, int64_t M, int Cin, int accumulate, void *stream) {
+    return yh_conv_pw_bwd_data_bn(dy1, cout1, dy2, cout2, lddy, wq, ldw, dx, lddx, M, Cin, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int yh_conv_pw_bwd_data_bn(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
+                                      float *dx, int lddx, int64_t M, int Cin, int accumulate, const void *bn_table, int n_bn,
+                                      void *stream) {
     YH_REQUIRE(dy1 && wq && dx && M > 0 && M < (1ll << 30) && cout1 > 0 && (dy2 ? cout2 > 0 : cout2 == 0) && lddx >= Cin,
                "conv_pw_bwd_data: bad argument");
+    YH_REQUIRE(n_bn >= 0 && n_bn <= 8 && (n_bn == 0 || bn_table), "conv_pw_bwd_data: bad BatchNorm table");
     PwG g{};
+    g.bn_tab = (const YhBnBwdEntry *)bn_table; g.bn_n = n_bn;
     g.in = dy1; g.in2 = dy2; g.Wq = wq; g.out = dx;
     g.ldi = lddy; g.ldw = ldw; g.ldo = lddx; g.M = (int)M; g.K = cout1 + cout2; g.K1 = cout1; g.N = Cin; g.accumulate = accumulate;
     return launch_pw_gemm(g, (hipStream_t)stream);

@@ -34,6 +34,8 @@ struct Wino {
     int TW, TPI, ntiles;        // tile columns per row, tiles per image, total tiles
     int ncol;                   // column blocks (set by the launcher)
     int accumulate;
+    const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns
+    int bn_n;
     unsigned tw_magic, tpi_magic;
     int tw_shift, tpi_shift;
 };
@@ -176,6 +178,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
     const bool nok = n < g.N;
     const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
     float csum = 0.f, csq = 0.f;
+    // BatchNorm-backward sums for the producer that owns this thread's column (see YhBnBwdEntry)
+    const float *ey = nullptr;
+    float *epart = nullptr;
+    int eC = 0, ecl = 0, eldy = 0;
+    float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
+    for (int e = 0; e < g.bn_n; ++e) {
+        const YhBnBwdEntry en = g.bn_tab[e];
+        if (nok && n >= en.col0 && n < en.col0 + en.ncol) {
+            ecl = n - en.col0; eC = en.C; eldy = en.ldy; ey = en.y + ecl; epart = en.part;
+            esc = en.coef[ecl]; esh = en.coef[eC + ecl]; emu = en.coef[2 * eC + ecl]; eis = en.coef[3 * eC + ecl];
+        }
+    }
     for (int it = 0; it < TPB / TG; ++it) {
         const int tl = tgp + TG * it, tg = tile0 + tl;
         if (tg >= g.ntiles) break;
@@ -195,21 +209,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             float *o0 = o + (size_t)j * g.ldo, *o1 = o0 + (size_t)g.W * g.ldo;
             if (g.accumulate) { y0 += *o0; y1 += *o1; }
             *o0 = y0; *o1 = y1;
-            csum += y0 + y1;
-            csq += y0 * y0 + y1 * y1;
+            if (ey) {
+                const size_t p0 = ((size_t)(b * g.H + 2 * ty) * g.W + 2 * tx + j) * eldy, p1 = p0 + (size_t)g.W * eldy;
+                yh_bn_bwd_accum(y0, ey[p0], esc, esh, emu, eis, csum, csq);
+                yh_bn_bwd_accum(y1, ey[p1], esc, esh, emu, eis, csum, csq);
+            } else {
+                csum += y0 + y1;
+                csq += y0 * y0 + y1 * y1;
+            }
         }
     }
-    if (g.stats) {
+    if (g.stats || g.bn_n) {
         float *red = smem + 4 * 2 * TPB * BNW;   // [TG][BNW][2]
         red[(tgp * BNW + ch) * 2 + 0] = csum;
         red[(tgp * BNW + ch) * 2 + 1] = csq;
         __syncthreads();
-        if (t < BNW && n0 + t < g.N) {
+        if (tgp == 0 && nok) {                   // ch == t: the thread that looked its column up
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int w = 0; w < TG; ++w) { a0 += red[(w * BNW + t) * 2]; a1 += red[(w * BNW + t) * 2 + 1]; }
-            g.stats[((size_t)tgrp * 2 + 0) * g.N + n0 + t] = a0;
-            g.stats[((size_t)tgrp * 2 + 1) * g.N + n0 + t] = a1;
+            if (g.stats) {
+                g.stats[((size_t)tgrp * 2 + 0) * g.N + n] = a0;
+                g.stats[((size_t)tgrp * 2 + 1) * g.N + n] = a1;
+            } else if (epart) {
+                epart[((size_t)tgrp * 2 + 0) * eC + ecl] = a0;
+                epart[((size_t)tgrp * 2 + 1) * eC + ecl] = a1;
+            }
         }
     }
 }
@@ -609,10 +634,21 @@ extern "C" int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu
     return launch_wino(g, (hipStream_t)stream);
 }
 
+extern "C" int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
+                                        int W, int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream);
+
 extern "C" int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                                      int W, int Cin, int Cout, int accumulate, void *stream) {
+    return yh_conv_wino_bwd_data_bn(dy, lddy, Ub, ldub, dx, lddx, B, H, W, Cin, Cout, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
+                                        int W, int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream) {
     YH_REQUIRE(dy && Ub && dx && B > 0 && H > 0 && W > 0 && lddy >= Cout && lddx >= Cin, "conv_wino_bwd_data: bad argument");
+    YH_REQUIRE(n_bn >= 0 && n_bn <= 8 && (n_bn == 0 || bn_table), "conv_wino_bwd_data: bad BatchNorm table");
+    static_assert(sizeof(YhBnBwdEntry) == 48, "record layout is part of the ABI");
     Wino g{};
+    g.bn_tab = (const YhBnBwdEntry *)bn_table; g.bn_n = n_bn;
     g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
     g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
     return launch_wino(g, (hipStream_t)stream);

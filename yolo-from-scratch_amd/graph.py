@@ -447,6 +447,8 @@ class Plan:
         ops: List[L.YhOp] = []
         pair_pending = set()
         self.grad_ready: Dict[int, int] = {}     # id(param) -> number of backward ops after which its grad is final
+        writers: List[tuple] = []                # (op index, view written, consumer rec | None): every op that writes an activation gradient
+        bn_ops: Dict[int, tuple] = {}            # id(rec) -> (rec, index of its REDUCE op, index of its APPLY op)
         for r in reversed(self.recs):
             if isinstance(r, SyncRec):
                 continue
@@ -455,6 +457,7 @@ class Plan:
                 if not acc:
                     raise NotImplementedError("max-pool backward expects an already written input gradient")
                 ops.append(_op(L.OP_MAXPOOL5_BWD, p=[r.out.gptr(), r.arg, dst], i=[r.out.ld, r.x.ld, r.x.B, r.x.H, r.x.W, r.x.C]))
+                writers.append((len(ops) - 1, r.x, None))
                 continue
             M = r.x.B * r.Ho * r.Wo
             if r.bn is not None:
@@ -470,6 +473,9 @@ class Plan:
                                p=[r.out.gptr(), r.y, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)],
                                   grad_of[id(r.bn.bias)], r.y, dres],
                                i=[r.out.ld, r.cout, nb, r.cout, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                bn_ops[id(r)] = (r, len(ops) - 2, len(ops) - 1)
+                if r.residual is not None:
+                    writers.append((len(ops) - 1, r.residual, None))
                 dy, lddy = r.y.data_ptr(), r.cout
                 self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
             else:
@@ -492,10 +498,12 @@ class Plan:
                     else:
                         ops.append(_op(L.OP_CONV_BWD_DATA_PAIR, p=[first.y, second.y, first.wb, dst],
                                        i=[first.cout, second.cout, first.cout, first.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, acc]))
+                    writers.append((len(ops) - 1, r.x, r))
                 else:
                     pair_pending.add(id(r))
             elif r.need_dx:
                 dst, acc = self._grad_target(r.x)
+                writers.append((len(ops), r.x, r))
                 if r.s2m_b:
                     ops.append(_op(L.OP_CONV_BWD_DATA_S2M, p=[dy, r.wb, dst],
                                    i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
@@ -508,7 +516,51 @@ class Plan:
                 else:
                     ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
                                    i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
+        # measured at bs=64: backward-data 5.74 -> 7.26 ms, reduce 1.27 -> 0.42 ms, net +0.8 ms/step -- the sums cost more in the
+        # serial epilogue of an MFMA-bound kernel than as a streaming pass at 5.5 TB/s -- so this is OFF unless asked for
+        if os.environ.get("YH_BN_EPI", "0") == "1":
+            self._fold_bn_reduce_into_writers(ops, writers, bn_ops, keep)
         return ops
+
+    def _fold_bn_reduce_into_writers(self, ops, writers, bn_ops, keep):
+        """BatchNorm backward, first pass (sum dz, sum dz*xhat over the batch): when the LAST op that writes a layer's
+        activation gradient is a Winograd / pointwise backward-data GEMM covering all of the layer's channels, that GEMM's
+        epilogue produces the sums (it holds the final gradient values in registers and reads the layer's y beside them) and the
+        separate reduce pass over dOut and y is dropped.  Everything else keeps the reduce kernel."""
+        import struct
+        lib = L.lib()
+        tables: Dict[int, list] = {}
+        for rec, ri, ai in bn_ops.values():
+            if rec.upsample:
+                continue
+            v = rec.out
+            lo, hi = v.off, v.off + v.C
+            cand = [(k, w, c) for (k, w, c) in writers if w.buf is v.buf and w.off < hi and lo < w.off + w.C and k < ri]
+            if not cand:
+                continue
+            k, w, c = max(cand, key=lambda t: t[0])
+            kind = ops[k].kind
+            if c is None or kind not in (L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_PW_BWD_DATA) or not (w.off <= lo and hi <= w.off + w.C):
+                continue
+            if len(tables.setdefault(k, [])) >= 8:
+                continue
+            M = w.B * w.H * w.W
+            rows = lib.yh_conv_wino_blocks(w.B, w.H, w.W) if kind == L.OP_CONV_WINO_BWD_DATA else lib.yh_conv_pw_blocks(M, w.C)
+            part = torch.empty(rows * 2 * rec.cout, device=self.device, dtype=torch.float32)
+            keep.append(part)
+            tables[k].append((rec.y.data_ptr(), rec.coef.data_ptr(), part.data_ptr(), lo - w.off, rec.cout, rec.cout, rec.cout, 0, 0))
+            ops[ri] = _op(L.OP_NOP)                       # indices of the following ops (gradient-bucket boundaries) stay valid
+            ops[ai].p[3] = part.data_ptr()                # the apply op finalises from the writer's partial rows
+            ops[ai].i[2] = rows
+        for k, ents in tables.items():
+            blob = b"".join(struct.pack("<QQQiiiiii", *e) for e in ents)
+            tab = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+            keep.append(tab)
+            if ops[k].kind == L.OP_CONV_WINO_BWD_DATA:
+                ops[k].p[3], ops[k].i[9] = tab.data_ptr(), len(ents)
+            else:
+                ops[k].p[4], ops[k].i[10] = tab.data_ptr(), len(ents)
+        self.bn_epilogue_layers = sum(len(e) for e in tables.values())
 
     # ---- execution ----------------------------------------------------------------------------
     def params_moved(self) -> bool:
