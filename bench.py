@@ -22,6 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NC, IMG, BATCH = 1, 640, 64          # BASELINE.json configs[1]
+# informational runs of the other configs' shapes in fp32 (never the default, never the reported metric):
+#   YH_BENCH_SHAPE=80,640,64  or  80,1280,16
+if os.environ.get("YH_BENCH_SHAPE"):
+    NC, IMG, BATCH = (int(v) for v in os.environ["YH_BENCH_SHAPE"].split(","))
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -180,11 +184,12 @@ def main():
     loss = trainer.loss_out[:4].tolist()
 
     result = {
-        "metric": "images/sec training step, 640x640 bs=64/GPU", "value": round(BATCH * world * args.steps / elapsed, 2),
+        "metric": "images/sec training step, 640x640 bs=64/GPU" if (NC, IMG, BATCH) == (1, 640, 64) else
+                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} (informational shape)", "value": round(BATCH * world * args.steps / elapsed, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "nc=1 640x640 bs=64/GPU full training step (fwd+loss+bwd+clip10+Adam), model size s, fp32 MFMA",
+        "config": {"workload": f"nc={NC} {IMG}x{IMG} bs={BATCH}/GPU full training step (fwd+loss+bwd+clip10+Adam), model size s, fp32 MFMA",
                    "global_batch": BATCH * world, "parallelism": f"dp{world}"},
         "loss": [round(v, 6) for v in loss],
     }
