@@ -115,7 +115,7 @@ int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, 
  * DEVICE array of n_bn (<= 8) 48-byte records { const float *y, *coef; float *partials; int32 col0, ncol, ldy, C, 0, 0 }:
  * output columns [col0, col0 + ncol) of dx are the C = ncol channels of a producer whose pre-BN output is y (pixel
  * stride ldy) and whose forward coefficients are coef (yh_bn_finalize); partials receives
- * [rows][2][C] with rows = yh_conv_wino_blocks(B,H,W) resp. yh_conv_pw_blocks(M, Cin), to be handed to
+ * [rows][2][C] with rows = yh_conv_wino_blocks(B,H,W) resp. yh_conv_pw_blocks(M, cout1 + cout2, Cin), to be handed to
  * yh_bn_silu_bwd_apply as its (partials, nblk).  Only valid when this call writes the FINAL value of those columns. */
 int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H, int W,
                              int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream);
@@ -139,17 +139,18 @@ int64_t yh_conv_pw_bwd_weight_ws(int64_t M, int Cin, int Cout);
  * (`table`: DEVICE array of 48-byte records { const float *oihw; float *wq_fwd, *wq_bwd; int32 Cout, Cin, ldw_fwd,
  * ldw_bwd, koff_bwd, noff_fwd }; either destination may be NULL; koff_bwd / noff_fwd = first K row / first column of this
  * conv inside a stacked backward / forward matrix; the forward pack writes only its own columns: allocate wq_fwd zeroed).  Channel counts feeding K must be multiples of 8.  yh_conv_pw_fwd: same contract as yh_conv_fwd
- * (k = 1), bn_partials [yh_conv_pw_blocks(M, Cout)][2][Cout].  yh_conv_pw_bwd_data: dx (+)= dy1 W1^T (+ dy2 W2^T when
+ * (k = 1), bn_partials [yh_conv_pw_blocks(M, Cin, Cout)][2][Cout] (K = the reduction length: small-K, many-pixel layers run a
+ * streaming form with one partial row per workgroup).  yh_conv_pw_bwd_data: dx (+)= dy1 W1^T (+ dy2 W2^T when
  * dy2 != NULL: the C3 sibling pair, K = cout1 + cout2 stacked in wq).
  * replaces: nn.Conv2d(k=1) forward and input gradient, train.py:236-240, 282-296, 402-418, 913. */
 int yh_pw_pack_multi(const void *table, int n, void *stream);
-int yh_conv_pw_blocks(int64_t M, int Cout);
+int yh_conv_pw_blocks(int64_t M, int K, int Cout);
 int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const float *bias, float *y, int ldy, float *bn_partials,
                    int64_t M, int Cin, int Cout, void *stream);
 /* Two sibling pointwise convolutions that read the same x (C3's conv1 / conv2, train.py:282-293) as ONE GEMM with
  * N = cout1 + cout2: wq holds both weight matrices side by side (pack records with noff = 0 and noff = cout1 into a
  * zero-initialised buffer), each output tensor keeps its own ld, bias and BatchNorm partials
- * [yh_conv_pw_blocks(M, cout1 + cout2)][2][cout_i]. */
+ * [yh_conv_pw_blocks(M, Cin, cout1 + cout2)][2][cout_i]. */
 int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw, const float *bias1, float *y1, int ldy1,
                     float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2, int cout2,
                     int64_t M, int Cin, void *stream);

@@ -32,7 +32,9 @@ def pack(L, lib, w, wq_f, wq_b, ldwf, ldwb, koff=0, noff=0):
     torch.cuda.synchronize()
 
 
-CASES = [(300, 32, 16), (1000, 64, 64), (777, 128, 128), (260, 256, 128), (513, 192, 64), (129, 64, 24), (4100, 32, 32), (96, 384, 136)]
+CASES = [(300, 32, 16), (1000, 64, 64), (777, 128, 128), (260, 256, 128), (513, 192, 64), (129, 64, 24), (4100, 32, 32), (96, 384, 136),
+         # M >= 32768 with small K: the streaming form (weights in registers, fixed grid, one partial row per workgroup)
+         (40003, 32, 32), (70001, 64, 64), (33000, 32, 128), (50000, 16, 16), (36000, 64, 24), (32768, 32, 16), (33000, 128, 32)]
 
 
 @pytest.mark.parametrize("M,Cin,Cout", CASES)
@@ -54,7 +56,7 @@ def test_pointwise_forward_and_backward_data(M, Cin, Cout):
     xb[:, offx:offx + Cin] = x.cuda()
     ldy, offy = Cout + 4, 4
     yb = torch.full((M, ldy), -2.0, device="cuda")
-    nblk = lib.yh_conv_pw_blocks(M, Cout)
+    nblk = lib.yh_conv_pw_blocks(M, Cin, Cout)
     part = torch.zeros(nblk, 2, Cout, device="cuda")
     L.check(lib.yh_conv_pw_fwd(xb.data_ptr() + 4 * offx, ldx, qf.data_ptr(), ldwf, bias.cuda().data_ptr(), yb.data_ptr() + 4 * offy, ldy,
                                part.data_ptr(), M, Cin, Cout, st))
@@ -75,7 +77,8 @@ def test_pointwise_forward_and_backward_data(M, Cin, Cout):
         assert lib.yh_conv_pw_bwd_data(dy.cuda().data_ptr(), Cout, None, 0, Cout, qb.data_ptr(), ldwb, xb.data_ptr(), ldx, M, Cin, 0, st) != 0
 
 
-@pytest.mark.parametrize("M,Cin,c1,c2", [(500, 64, 32, 32), (1300, 32, 16, 16), (260, 256, 128, 128), (333, 128, 64, 40)])
+@pytest.mark.parametrize("M,Cin,c1,c2", [(500, 64, 32, 32), (1300, 32, 16, 16), (260, 256, 128, 128), (333, 128, 64, 40),
+                                         (45000, 64, 32, 32), (60001, 32, 16, 16)])          # last two: streaming form
 def test_pointwise_sibling_pair_forward_and_backward_data(M, Cin, c1, c2):
     """two convs reading the same x: fused forward (two outputs, own bias / partial sums) and fused backward-data (K from
     two tensors) equal the two separate convolutions"""
@@ -95,7 +98,7 @@ def test_pointwise_sibling_pair_forward_and_backward_data(M, Cin, c1, c2):
     pack(L, lib, w2d, q, qb, ldw, ldwb, koff=c1, noff=c1)
     xd = x.cuda()
     y1, y2 = torch.empty(M, c1, device="cuda"), torch.full((M, c2 + 4), 9.0, device="cuda")
-    nblk = lib.yh_conv_pw_blocks(M, c1 + c2)
+    nblk = lib.yh_conv_pw_blocks(M, Cin, c1 + c2)
     p1, p2 = torch.zeros(nblk, 2, c1, device="cuda"), torch.zeros(nblk, 2, c2, device="cuda")
     L.check(lib.yh_conv_pw_fwd2(xd.data_ptr(), Cin, q.data_ptr(), ldw, None, y1.data_ptr(), c1, p1.data_ptr(), c1, b2.cuda().data_ptr(),
                                 y2.data_ptr(), c2 + 4, p2.data_ptr(), c2, M, Cin, st))

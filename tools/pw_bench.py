@@ -73,7 +73,7 @@ def main():
         y0, y1 = torch.empty(M, Cout, device=dev), torch.empty(M, Cout, device=dev)
         dx0, dx1 = torch.empty(M, Cin, device=dev), torch.empty(M, Cin, device=dev)
         p0 = torch.empty(lib.yh_conv_fwd_blocks(B, H, W, Cout, 1, 1) * 2 * Cout, device=dev)
-        nb1 = lib.yh_conv_pw_blocks(M, Cout)
+        nb1 = lib.yh_conv_pw_blocks(M, Cin, Cout)
         p1 = torch.empty(nb1 * 2 * Cout, device=dev)
         f_dir = lambda: L.check(lib.yh_conv_fwd(x.data_ptr(), Cin, wf.data_ptr(), ldwf, bias.data_ptr(), y0.data_ptr(), Cout,
                                                 p0.data_ptr(), B, H, W, Cin, Cout, 1, 1, st))

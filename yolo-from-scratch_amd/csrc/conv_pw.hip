@@ -381,6 +381,147 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
     }
 }
 
+// Small-K, small-N, many-pixel pointwise layers (the 160^2 / 80^2 1x1 convs: K <= 64, memory-bound): a STREAMING form of the
+// same GEMM.  All B fragments of the layer (K/8 x NT float4 per lane) are loaded once and stay in registers; a fixed grid of
+// workgroups walks the pixel groups (32 pixels per wave and trip), prefetching the next group's A operand while the
+// current one is multiplied and stored.  No per-tile prologue, one BatchNorm partial row per workgroup (<= 1024 rows to
+// finalize instead of M / 128).
+template <int NT, int KC>
+__global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
+    __shared__ float red[4][32 * NT][2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g.in, 0, g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void *)(g.in2 ? g.in2 : g.in), 0, g.in2 ? g.in2_bytes : 0u, 0x00020000);
+    const int kc1 = g.K1 >> 3;
+
+    f32x4 b[KC][NT];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 32 + lr;
+            b[c][j] = *(const f32x4 *)(g.Wq + ((size_t)(2 * c + lh) * g.ldw + (n < g.ldw ? n : 0)) * 4);
+        }
+    // per-column epilogue state (same semantics as pw_gemm_kernel)
+    bool nok[NT];
+    float bias[NT], esc[NT], esh[NT], emu[NT], eis[NT], csum[NT], csq[NT];
+    float *ob[NT];
+    const float *ey[NT];
+    int ldo[NT], eldy[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + lr;
+        nok[j] = n < g.N;
+        const bool second = n >= g.N1;
+        const int nl = second ? n - g.N1 : n;
+        const float *bp = second ? g.bias2 : g.bias;
+        bias[j] = (bp && nok[j]) ? bp[nl] : 0.f;
+        ob[j] = (second ? g.out2 : g.out) + nl;
+        ldo[j] = second ? g.ldo2 : g.ldo;
+        ey[j] = nullptr; eldy[j] = 0; esc[j] = esh[j] = emu[j] = eis[j] = 0.f; csum[j] = csq[j] = 0.f;
+        for (int e = 0; e < g.bn_n; ++e) {
+            const YhBnBwdEntry en = g.bn_tab[e];
+            if (nok[j] && n >= en.col0 && n < en.col0 + en.ncol) {
+                const int cl = n - en.col0;
+                eldy[j] = en.ldy; ey[j] = en.y + cl;
+                esc[j] = en.coef[cl]; esh[j] = en.coef[en.C + cl]; emu[j] = en.coef[2 * en.C + cl]; eis[j] = en.coef[3 * en.C + cl];
+            }
+        }
+    }
+
+    const int ngroups = (g.M + 31) >> 5, stride = gridDim.x * 4;
+    auto load = [&](int grp, f32x4 (&a)[KC]) {
+        const int p = grp * 32 + lr;
+        const unsigned off = (((unsigned)p * (unsigned)g.ldi + 4u * lh) * 4u) | ((unsigned)(p >= g.M || grp >= ngroups) << 31);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) a[c] = c < kc1 ? buf_load<4>(r1, off + (unsigned)c * 32u) : buf_load<4>(r2, off + (unsigned)(c - kc1) * 32u);
+    };
+    auto compute = [&](int grp, const f32x4 (&a)[KC]) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][e], b[c][j][e], acc[j], 0, 0, 0);
+        const int p0 = grp * 32;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nok[j] && p < g.M) {
+                    float *o = ob[j] + (size_t)p * ldo[j];
+                    float v = acc[j][r] + bias[j];
+                    if (g.accumulate) v += *o;
+                    *o = v;
+                    if (ey[j]) {
+                        yh_bn_bwd_accum(v, ey[j][(size_t)p * eldy[j]], esc[j], esh[j], emu[j], eis[j], csum[j], csq[j]);
+                    } else {
+                        csum[j] += v;
+                        csq[j] += v * v;
+                    }
+                }
+            }
+    };
+    f32x4 aA[KC], aB[KC];
+    int grp = blockIdx.x * 4 + wave;
+    load(grp, aA);
+    for (; grp < ngroups; grp += 2 * stride) {
+        load(grp + stride, aB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(grp, aA);
+        __builtin_amdgcn_sched_barrier(0);
+        load(grp + 2 * stride, aA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp + stride < ngroups) compute(grp + stride, aB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (g.stats || g.bn_n) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) { red[wave][j * 32 + lr][0] = s; red[wave][j * 32 + lr][1] = q; }
+        }
+        __syncthreads();
+        if (t < 32 * NT && t < g.N) {
+            float a0 = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
+            float a1 = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
+            const int n = t;
+            if (!g.stats) {
+                for (int e = 0; e < g.bn_n; ++e) {
+                    const YhBnBwdEntry en = g.bn_tab[e];
+                    if (n >= en.col0 && n < en.col0 + en.ncol) {
+                        en.part[((size_t)blockIdx.x * 2 + 0) * en.C + n - en.col0] = a0;
+                        en.part[((size_t)blockIdx.x * 2 + 1) * en.C + n - en.col0] = a1;
+                    }
+                }
+                return;
+            }
+            float *sp = n >= g.N1 ? g.stats2 : g.stats;
+            const int C = n >= g.N1 ? g.N - g.N1 : g.N1, nl = n >= g.N1 ? n - g.N1 : n;
+            sp[((size_t)blockIdx.x * 2 + 0) * C + nl] = a0;
+            sp[((size_t)blockIdx.x * 2 + 1) * C + nl] = a1;
+        }
+    }
+}
+
+// streaming form: K in {16, 32, 64}, N <= 64 and enough pixels to stream (measured: 160^2 32->32 0.104 -> 0.085 ms = 4.9 TB/s;
+// N = 128 with K = 32 was slower than the tiled kernel and is left to it)
+inline bool pw_use_stream(int64_t M, int K, int N) {
+    static const bool on = !(getenv("YH_PW_STREAM") && atoi(getenv("YH_PW_STREAM")) == 0);
+    return on && M >= 32768 && (K == 16 || K == 32 || K == 64) && N <= 64;
+}
+inline int pw_stream_blocks(int64_t M) {
+    int64_t b = ((M + 31) / 32 + 3) / 4;
+    return (int)(b > 1024 ? 1024 : b);
+}
+
 struct PwPackDesc {
     const float *w;             // [Cout][Cin] (OIHW, 1x1)
     float *wf, *wb;             // forward: Wq[Cin/4][ldwf][4]; backward-data: Wq[(koff + Cout)/4 rows...][ldwb][4]
@@ -413,6 +554,19 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
     g.in_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + g.K1) * 4);
     g.in2_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + (g.K - g.K1)) * 4);
     const int NT = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
+    if (pw_use_stream(g.M, g.K, g.N)) {
+        dim3 sg(pw_stream_blocks(g.M));
+        const int KC = g.K / 8;
+#define YH_PWS(nt, kc) hipLaunchKernelGGL((pw_stream_kernel<nt, kc>), sg, dim3(256), 0, st, g)
+        bool ok = true;
+        if (NT == 1) { if (KC == 2) YH_PWS(1, 2); else if (KC == 4) YH_PWS(1, 4); else if (KC == 8) YH_PWS(1, 8); else ok = false; }
+        else if (NT == 2) { if (KC == 2) YH_PWS(2, 2); else if (KC == 4) YH_PWS(2, 4); else if (KC == 8) YH_PWS(2, 8); else ok = false; }
+        else ok = false;
+#undef YH_PWS
+        YH_REQUIRE(ok, "conv_pw: streaming form needs K in {16, 32, 64}");
+        YH_CHECK_LAUNCH("pw_stream");
+        return 0;
+    }
     const int TM = (NT <= 2 && cdiv(g.M, 256) * cdiv(g.N, 32 * NT) >= 1024) ? 2 : 1;   // <2,4> would run one wave per SIMD
     dim3 grid(cdiv(g.M, 128 * TM), cdiv(g.N, 32 * NT));
 #define YH_PWG(tm, nt) hipLaunchKernelGGL((pw_gemm_kernel<tm, nt>), grid, dim3(256), 0, st, g)
@@ -425,7 +579,8 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int yh_conv_pw_blocks(int64_t M, int Cout) {
+extern "C" int yh_conv_pw_blocks(int64_t M, int K, int Cout) {
+    if (pw_use_stream(M, K, Cout)) return pw_stream_blocks(M);
     const int NT = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
     const int TM = (NT <= 2 && cdiv((int)M, 256) * cdiv(Cout, 32 * NT) >= 1024) ? 2 : 1;
     return cdiv((int)M, 128 * TM);

@@ -346,7 +346,7 @@ class Plan:
 
                 if r.fwd2:
                     if r.pair_first:      # both siblings in one launch, at the first one's position in the list
-                        nblk = lib.yh_conv_pw_blocks(M, r.cout + r.pair.cout)
+                        nblk = lib.yh_conv_pw_blocks(M, r.cin, r.cout + r.pair.cout)
                         alloc_out(r, nblk)
                         alloc_out(r.pair, nblk)
                         q = r.pair
@@ -360,7 +360,7 @@ class Plan:
                             raise NotImplementedError("fused sibling convolution traced on the side lane without a preceding fork")
                 else:
                     nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
-                        lib.yh_conv_pw_blocks(M, r.cout) if r.pw_f else \
+                        lib.yh_conv_pw_blocks(M, r.cin, r.cout) if r.pw_f else \
                         lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
                         lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                     alloc_out(r, nblk)
@@ -545,7 +545,8 @@ class Plan:
             if len(tables.setdefault(k, [])) >= 8:
                 continue
             M = w.B * w.H * w.W
-            rows = lib.yh_conv_wino_blocks(w.B, w.H, w.W) if kind == L.OP_CONV_WINO_BWD_DATA else lib.yh_conv_pw_blocks(M, w.C)
+            rows = lib.yh_conv_wino_blocks(w.B, w.H, w.W) if kind == L.OP_CONV_WINO_BWD_DATA else \
+                lib.yh_conv_pw_blocks(M, c.cout + (c.pair.cout if c.pair is not None else 0), w.C)
             part = torch.empty(rows * 2 * rec.cout, device=self.device, dtype=torch.float32)
             keep.append(part)
             tables[k].append((rec.y.data_ptr(), rec.coef.data_ptr(), part.data_ptr(), lo - w.off, rec.cout, rec.cout, rec.cout, 0, 0))
