@@ -13,7 +13,7 @@ import glob
 import json
 import sys
 
-CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "stem_conv_kernel")
+CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_stream_kernel", "stem_conv_kernel")
 WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "pw_wgrad_kernel")
 
 
@@ -49,7 +49,7 @@ def main():
     total = lambda part: res["fetch"][part] * corr + res["write"][part]
     doc = {
         "kernels": f"forward convolutions of one bs=64 step: {res['fetch']['n_fwd']} launches "
-                   "(gather_gemm_kernel + wino_kernel + pw_gemm_kernel + stem_conv_kernel)",
+                   "(gather_gemm_kernel + wino_kernel + pw_gemm_kernel + pw_stream_kernel + stem_conv_kernel)",
         "fetch_size_bytes_raw": res["fetch"]["fwd"], "fetch_correction": corr, "write_size_bytes": res["write"]["fwd"],
         "hbm_bytes_per_step": total("fwd"),
         "hbm_bytes_per_step_by_kernel": {k: res["fetch"]["by_kernel_fwd"][k] * corr + res["write"]["by_kernel_fwd"][k] for k in CONV},

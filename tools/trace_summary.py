@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "stem_conv_kernel")
+CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_stream_kernel", "stem_conv_kernel")
 
 
 def main():
