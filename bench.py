@@ -50,7 +50,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
     st = torch.cuda.current_stream(dev).cuda_stream
     conv_ms, n_launch = 0.0, 0
     per_kind = {}
-    L.lib().yh_set_overlap(0)        # every launch on the timed stream while instrumenting
+    L.set_overlap(0, dev.index)        # every launch on the timed stream while instrumenting
     for _ in range(steps):
         trainer.model._load_input(plan, imgs)
         evs = []
@@ -71,7 +71,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
     # the whole forward op list in ONE yh_run call (no per-op events between the launches): serial, then with the lanes on
     whole = {}
     for name, ov in (("serial", 0), ("lanes", 1)):
-        L.lib().yh_set_overlap(ov)
+        L.set_overlap(ov, dev.index)
         tot = 0.0
         for _ in range(steps):
             trainer.model._load_input(plan, imgs)
@@ -82,7 +82,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
             torch.cuda.synchronize(dev)
             tot += e0.elapsed_time(e1)
         whole[name] = tot / steps
-    L.lib().yh_set_overlap(1)
+    L.set_overlap(1, dev.index)
     per = {k: v / steps for k, v in per_kind.items()}
     per["whole_forward_serial"], per["whole_forward_lanes"] = whole["serial"], whole["lanes"]
     return conv_ms / steps, n_launch // steps, per

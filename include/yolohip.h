@@ -27,7 +27,26 @@ extern "C" {
 #define YH_E_WORKSPACE (-3)
 
 int yh_version(void);
-const char *yh_last_error(void);
+const char *yh_last_error(void);    /* per host thread */
+
+/* ---- execution context ------------------------------------------------------------------------ */
+/* The only state the library keeps between calls lives in an explicit handle: the side HIP stream
+ * and the fork / join events yh_run uses to overlap independent work.  A context binds to the device that is
+ * current at its first run that needs the side lane (calls with another device current are then refused);
+ * it serves ONE host thread at a time; distinct contexts share nothing, so concurrent yh_run calls on distinct
+ * contexts and streams are safe.  yh_create itself makes no HIP call (it works on a host without a GPU).
+ * Every other entry point is stateless apart from the per-thread error string and a mutex-guarded
+ * (device, kernel) table of dynamic-LDS opt-ins.
+ * replaces: nothing in the reference (ATen's stream/event pool is implicit there). */
+typedef struct yh_context yh_context;
+int yh_create(yh_context **out);
+int yh_destroy(yh_context *ctx);          /* waits for the side stream, then frees it; NULL is a no-op */
+/* enable = 0: yh_run executes every op in list order on the caller's stream (default: on, or YH_OVERLAP=0) */
+int yh_context_set_overlap(yh_context *ctx, int enable);
+/* introspection for tests: bound device (-1 = not bound yet), overlap flag (-1 = undecided), raw handles (NULL
+ * until the first forked run); any output pointer may be NULL */
+int yh_context_info(const yh_context *ctx, int *device, int *overlap, void **side_stream, void **fork_event,
+                    void **join_event);
 
 /* ---- layout ------------------------------------------------------------------------------- */
 /* NCHW (B,C,H,W) -> NHWC with ld floats per pixel (channels >= C are zero filled up to cpad).
@@ -305,14 +324,13 @@ enum {
     YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M, YH_OP_CONV_PW_FWD2, YH_OP_NOP
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
- * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on an internal side
+ * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side
  * stream, ordered against the caller's stream only at YH_OP_FORK / YH_OP_JOIN records (independent
  * sub-graphs, e.g. detection heads next to the neck).  Backward-weight and column-sum ops are forked
- * automatically (they only feed the optimiser).  Everything is joined back into `stream` before the call
- * returns, so stream order is preserved for the caller; yh_set_overlap(0) (or YH_OVERLAP=0) runs the
- * whole list in order on `stream`. */
-int yh_run(const yh_op *ops, int n, void *stream, int *failed);
-int yh_set_overlap(int enable);
+ * automatically (they only feed the optimiser).  Everything launched is joined back into `stream` before the
+ * call returns -- also when an op fails -- so stream order is preserved for the caller.  ctx == NULL (or
+ * yh_context_set_overlap(ctx, 0), or YH_OVERLAP=0) runs the whole list in order on `stream`. */
+int yh_run(yh_context *ctx, const yh_op *ops, int n, void *stream, int *failed);
 
 #ifdef __cplusplus
 }

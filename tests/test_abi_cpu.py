@@ -112,3 +112,62 @@ def test_checkpoint_round_trip_and_reference_style_grid_buffers(tmp_path):
     torch.save({**ck, "model": sd}, p)
     m3, _ = y.load_checkpoint(p)
     assert torch.equal(m3.grid_x_p3, gx.view(1, g, g, 1))
+
+
+def test_fused_step_rejects_mismatched_targets():
+    """HipTrainer.step hands raw pointers to yh_yolo_loss: targets of the wrong device / dtype / shape must raise
+    before anything is launched (the reference raises a shape error in its loss, train.py:806-830)."""
+    from yolo_from_scratch_amd.training import check_targets
+    shapes = [(2, 8, 8, 3, 6), (2, 4, 4, 3, 6), (2, 2, 2, 3, 6)]
+    good = [torch.zeros(s) for s in shapes]
+    with pytest.raises(ValueError, match="no CPU fallback"):           # host tensors
+        check_targets(good, shapes, "cuda:0")
+    with pytest.raises(ValueError, match="expected 3 target tensors"):
+        check_targets(good[:2], shapes, "cuda:0")
+    meta = [torch.empty(s, device="meta") for s in shapes]             # shape / dtype rules, checked without a GPU
+    import unittest.mock as mock
+
+    def as_cuda(t, dtype=torch.float32, shape=None):
+        m = mock.MagicMock(spec=torch.Tensor)
+        m.device, m.dtype, m.shape = torch.device("cuda:0"), dtype, torch.Size(shape if shape is not None else t.shape)
+        m.contiguous.return_value = m
+        return m
+
+    ok = check_targets([as_cuda(t) for t in meta], shapes, "cuda:0")
+    assert len(ok) == 3
+    with pytest.raises(ValueError, match="float32"):
+        check_targets([as_cuda(meta[0], torch.float64)] + [as_cuda(t) for t in meta[1:]], shapes, "cuda:0")
+    with pytest.raises(ValueError, match="has shape"):                 # smaller last batch vs the plan's batch
+        check_targets([as_cuda(meta[0], shape=(1, 8, 8, 3, 6))] + [as_cuda(t) for t in meta[1:]], shapes, "cuda:0")
+    with pytest.raises(ValueError, match="has shape"):                 # built for another num_classes
+        check_targets([as_cuda(meta[0], shape=(2, 8, 8, 3, 8))] + [as_cuda(t) for t in meta[1:]], shapes, "cuda:0")
+
+
+def test_contexts_are_independent_handles():
+    """the only state between calls lives in the explicit yh_context.  Two handles share nothing: own
+    overlap flag, own (lazily created) side stream / events; yh_create makes no HIP call so this runs without a GPU.
+    The GPU half (distinct stream / event handles once bound, two host threads on two streams) is
+    tests/test_gpu_api_surface.py::test_two_contexts_two_streams."""
+    from yolo_from_scratch_amd import _lib as L
+    a, b = L.Context(), L.Context()
+    assert a.handle.value != b.handle.value
+    assert a.info() == {"device": -1, "overlap": -1, "side_stream": None, "fork_event": None, "join_event": None}
+    a.set_overlap(False)
+    assert a.info()["overlap"] == 0 and b.info()["overlap"] == -1          # b untouched
+    b.set_overlap(True)
+    assert a.info()["overlap"] == 0 and b.info()["overlap"] == 1
+    # an empty list, and a list of lane markers only, run without touching a device
+    ops = (L.YhOp * 2)()
+    ops[0].kind, ops[1].kind = L.OP_FORK, L.OP_JOIN
+    L.run_ops(ops, 0, 0, a)
+    L.run_ops(ops, 2, 0, a)                  # overlap off: markers are skipped
+    L.run_ops(ops, 2, 0, None)               # no context: serial
+    # a failing op reports its index and the message; the context stays usable
+    bad = (L.YhOp * 2)()
+    bad[0].kind, bad[1].kind = L.OP_NOP, 9999
+    with pytest.raises(RuntimeError, match=r"op #1 \(kind 9999\).*unknown op kind"):
+        L.run_ops(bad, 2, 0, a)
+    L.run_ops(ops, 2, 0, a)
+    assert L.context_for(0) is L.context_for(0) and L.context_for(0) is not L.context_for(1)
+    a.close(); b.close()
+    assert a.handle is None

@@ -236,3 +236,59 @@ def test_predict_batch_equals_predict_per_image(tmp_path, nc):
     assert y.predict_batch(model, [], dev, nc) == []
     again = y.predict_batch(model, paths[:2], dev, nc, conf_threshold=0.3, iou_threshold=0.4)     # smaller batch reuses buffers
     assert again == single[:2]
+
+
+def test_two_contexts_two_streams():
+    """Two host threads, each with its own model, HIP stream and (per-thread) yh_context, run forward passes
+    concurrently: the contexts bind distinct side streams / events and every result equals the single-threaded
+    one bit for bit.  An op failure on a context with the side lane forked leaves the context usable (joined)."""
+    import threading
+    from yolo_from_scratch_amd import _lib as L
+    y = api()
+    dev = torch.device("cuda:0")
+    xs = [torch.rand(2, 3, 160, 160, generator=torch.Generator().manual_seed(5 + i)).to(dev) for i in range(2)]
+    models = []
+    for i in range(2):
+        torch.manual_seed(i)
+        models.append(y.YOLO(num_classes=2, img_size=160).to(dev).train())
+    with torch.no_grad():
+        want = [[o.clone() for o in m(x)] for m, x in zip(models, xs)]
+    torch.cuda.synchronize()
+    got, infos, errs = [None, None], [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(dev)
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(5):
+                    out = [o.clone() for o in models[i](xs[i])]
+            st.synchronize()
+            got[i] = out
+            infos[i] = L.context_for(0).info()          # this thread's default context
+        except Exception as e:                            # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(2):
+        for a, b in zip(got[i], want[i]):
+            assert torch.equal(a, b)
+    a, b = infos
+    assert a["device"] == b["device"] == 0
+    for k in ("side_stream", "fork_event", "join_event"):
+        assert a[k] and b[k] and a[k] != b[k], k
+    # failure with the side lane forked: FORK, a side-lane NOP, then an unknown op -> error, lane joined, context reusable
+    ctx = L.Context()
+    ops = (L.YhOp * 3)()
+    ops[0].kind = L.OP_FORK
+    ops[1].kind, ops[1].lane = L.OP_NOP, 1
+    ops[2].kind = 9999
+    st = torch.cuda.current_stream(dev).cuda_stream
+    with pytest.raises(RuntimeError, match=r"op #2"):
+        L.run_ops(ops, 3, st, ctx)
+    L.run_ops(ops, 2, st, ctx)
+    torch.cuda.synchronize()
+    assert ctx.info()["side_stream"]
+    ctx.close()

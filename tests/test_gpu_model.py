@@ -270,13 +270,13 @@ def test_side_lanes_do_not_change_results_and_trajectory_tracks_oracle():
     targets = y.synthetic_targets(B, nc, S, 8, 22)
     runs = []
     for overlap in (1, 0):
-        L.lib().yh_set_overlap(overlap)
+        L.set_overlap(overlap)
         torch.manual_seed(0)
         m = y.YOLO(num_classes=nc, img_size=S).cuda()
         tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
         losses = [tr.step(x.cuda(), [t.cuda() for t in targets])[:4].cpu().clone() for _ in range(3)]
         runs.append((tr.flat_p.clone(), torch.stack(losses)))
-    L.lib().yh_set_overlap(1)
+    L.set_overlap(1)
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
     torch.manual_seed(0)
     ref = y.YOLO(num_classes=nc, img_size=S)

@@ -103,8 +103,11 @@ _SIGS = {
     "yh_adam_step": (i32, [c_fp, c_fp, c_fp, c_fp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, c_fp, f32, c_fp]),
     "yh_memset": (i32, [c_fp, i32, i64, c_fp]),
     "yh_add_int64": (i32, [c_fp, i64, c_fp]),
-    "yh_run": (i32, [C.POINTER(YhOp), i32, c_fp, C.POINTER(i32)]),
-    "yh_set_overlap": (i32, [i32]),
+    "yh_run": (i32, [c_fp, C.POINTER(YhOp), i32, c_fp, C.POINTER(i32)]),
+    "yh_create": (i32, [C.POINTER(c_fp)]),
+    "yh_destroy": (i32, [c_fp]),
+    "yh_context_set_overlap": (i32, [c_fp, i32]),
+    "yh_context_info": (i32, [c_fp, C.POINTER(i32), C.POINTER(i32), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp)]),
 }
 
 _lib = None
@@ -153,9 +156,60 @@ def floats(vals):
     return arr
 
 
-def run_ops(ops, n: int, stream: int):
+class Context:
+    """Owner of one `yh_context` (side stream + fork/join events of yh_run).  One per (device, host thread) is
+    handed out by `context_for`; create your own for an extra concurrent stream."""
+
+    def __init__(self):
+        h = c_fp()
+        check(lib().yh_create(C.byref(h)), "create")
+        self.handle = h
+
+    def set_overlap(self, enable: bool):
+        check(lib().yh_context_set_overlap(self.handle, int(bool(enable))), "context_set_overlap")
+
+    def info(self) -> dict:
+        dev, ov = i32(-2), i32(-2)
+        side, fork, join = c_fp(), c_fp(), c_fp()
+        check(lib().yh_context_info(self.handle, C.byref(dev), C.byref(ov), C.byref(side), C.byref(fork), C.byref(join)),
+              "context_info")
+        return {"device": dev.value, "overlap": ov.value, "side_stream": side.value, "fork_event": fork.value,
+                "join_event": join.value}
+
+    def close(self):
+        if self.handle is not None and _lib is not None:
+            _lib.yh_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context_for(device_index: int) -> Context:
+    """The default execution context of this host thread for one device."""
+    import threading
+    key = (int(device_index), threading.get_ident())
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context()
+    return ctx
+
+
+def set_overlap(enable: bool, device_index: int = 0):
+    """Lanes on/off for this thread's default context of a device (bench instrumentation, A/B tests)."""
+    context_for(device_index).set_overlap(enable)
+
+
+def run_ops(ops, n: int, stream: int, ctx: "Context" = None):
+    """yh_run on `stream`; ctx = None runs every op in list order on that stream (no side lane)."""
     failed = i32(-1)
-    rc = lib().yh_run(ops, n, stream, C.byref(failed))
+    rc = lib().yh_run(ctx.handle if ctx is not None else None, ops, n, stream, C.byref(failed))
     if rc != 0:
         msg = lib().yh_last_error().decode(errors="replace")
         raise RuntimeError(f"libyolohip op #{failed.value} (kind {ops[failed.value].kind}) failed (code {rc}): {msg}")

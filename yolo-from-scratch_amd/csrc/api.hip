@@ -2,6 +2,9 @@
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
+#include <new>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -122,27 +125,101 @@ static int run_one(const yh_op &o, void *st) {
     }
 }
 
-// Weight-gradient work (backward-weight GEMMs, bias column sums) depends only on dY and on saved
-// activations, never on the rest of the backward chain, and nothing but the optimiser reads its
-// results.  yh_run therefore forks those ops onto a side stream (event fork after the op that produced
-// dY, event join before returning control): the MFMA-bound weight gradients overlap the HBM-bound
-// BatchNorm backward passes and fill the tail rounds of the backward-data GEMMs.
-static int g_overlap = -1;
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_fork = nullptr, g_join = nullptr;
+// ---- per-(device, kernel) dynamic-LDS opt-in ----------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and must precede the first launch that needs more than
+// the default.  The launchers call this helper instead of keeping function-local "already set" flags: one mutex-guarded
+// table keyed by (device, kernel), so two host threads or two devices cannot race or skip each other's opt-in.
+namespace {
+struct SmemKey {
+    int dev;
+    const void *fn;
+    size_t bytes;
+};
+std::mutex g_smem_mu;
+std::vector<SmemKey> g_smem;
+}  // namespace
 
-extern "C" int yh_set_overlap(int enable) {
-    g_overlap = enable ? 1 : 0;
+int yh_ensure_dyn_smem(const void *fn, size_t bytes) {
+    int dev = 0;
+    YH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_smem_mu);
+    for (SmemKey &k : g_smem)
+        if (k.dev == dev && k.fn == fn) {
+            if (k.bytes >= bytes) return 0;
+            YH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            k.bytes = bytes;
+            return 0;
+        }
+    YH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    g_smem.push_back(SmemKey{dev, fn, bytes});
     return 0;
 }
 
-static int side_ready() {
-    if (g_overlap < 0) {
-        const char *e = getenv("YH_OVERLAP");
-        g_overlap = (e && e[0] == '0') ? 0 : 1;
+// ---- execution context ("no global mutable state besides the explicit handle") ---------------------------
+// Weight-gradient work (backward-weight GEMMs, bias column sums) depends only on dY and on saved activations, never on
+// the rest of the backward chain, and nothing but the optimiser reads its results.  yh_run therefore forks those ops
+// onto the context's side stream (event fork after the op that produced dY, event join before returning control): the
+// MFMA-bound weight gradients overlap the HBM-bound BatchNorm backward passes and fill the tail rounds of the
+// backward-data GEMMs.  The side stream and its two events belong to ONE yh_context, bound to the device that was
+// current at its first forked run; a context serves one host thread at a time, distinct contexts are independent.
+struct yh_context {
+    int device = -1;            // bound lazily, at the first run that needs the side lane
+    int overlap = -1;           // -1: take YH_OVERLAP from the environment at first use
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+extern "C" int yh_create(yh_context **out) {
+    YH_REQUIRE(out, "yh_create: null output");
+    *out = new (std::nothrow) yh_context();
+    YH_REQUIRE(*out, "yh_create: out of memory");
+    return 0;
+}
+
+extern "C" int yh_destroy(yh_context *ctx) {
+    if (!ctx) return 0;
+    int rc = 0;
+    if (ctx->side) {
+        int cur = 0;
+        bool sw = hipGetDevice(&cur) == hipSuccess && cur != ctx->device && hipSetDevice(ctx->device) == hipSuccess;
+        if (hipStreamSynchronize(ctx->side) != hipSuccess) rc = YH_E_BADARG;
+        (void)hipEventDestroy(ctx->fork);
+        (void)hipEventDestroy(ctx->join);
+        (void)hipStreamDestroy(ctx->side);
+        if (sw) (void)hipSetDevice(cur);
     }
-    if (!g_overlap) return 0;
-    if (!g_side) {
+    delete ctx;
+    return rc;
+}
+
+extern "C" int yh_context_set_overlap(yh_context *ctx, int enable) {
+    YH_REQUIRE(ctx, "yh_context_set_overlap: null context");
+    ctx->overlap = enable ? 1 : 0;
+    return 0;
+}
+
+extern "C" int yh_context_info(const yh_context *ctx, int *device, int *overlap, void **side_stream, void **fork_event,
+                               void **join_event) {
+    YH_REQUIRE(ctx, "yh_context_info: null context");
+    if (device) *device = ctx->device;
+    if (overlap) *overlap = ctx->overlap;
+    if (side_stream) *side_stream = (void *)ctx->side;
+    if (fork_event) *fork_event = (void *)ctx->fork;
+    if (join_event) *join_event = (void *)ctx->join;
+    return 0;
+}
+
+// 1 = the side lane is usable for this run, 0 = run everything in list order on the caller's stream, < 0 = error
+static int side_ready(yh_context *ctx) {
+    if (!ctx) return 0;
+    if (ctx->overlap < 0) {
+        const char *e = getenv("YH_OVERLAP");
+        ctx->overlap = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!ctx->overlap) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (!ctx->side) {
         // YH_SIDE_PRIORITY=low|high: experiment knob.  A low-priority side lane measured 22.21 -> 22.12 ms/step in training
         // (noise level) but a captured hipGraph with mixed-priority nodes replays 2x slower (2.4 -> 4.8 ms at bs=1), so the
         // default is an ordinary stream.
@@ -150,59 +227,77 @@ static int side_ready() {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = numerically greatest = lowest priority
         const char *pr = getenv("YH_SIDE_PRIORITY");
         hipError_t e = (pr && (pr[0] == 'l' || pr[0] == 'h'))
-                           ? hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, pr[0] == 'l' ? lo : hi)
-                           : hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
-        if (e != hipSuccess ||
-            hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) {
-            g_side = nullptr;
-            g_overlap = 0;
+                           ? hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, pr[0] == 'l' ? lo : hi)
+                           : hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+        if (e != hipSuccess || hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming) != hipSuccess) {
+            if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+            if (ctx->side) (void)hipStreamDestroy(ctx->side);
+            ctx->side = nullptr;
+            ctx->fork = ctx->join = nullptr;
+            ctx->overlap = 0;
             return 0;
         }
+        ctx->device = dev;
+    }
+    if (dev != ctx->device) {
+        yh_set_error("yh_run: context is bound to device %d but device %d is current (one context per device)", ctx->device, dev);
+        return YH_E_BADARG;
     }
     return 1;
 }
 
-extern "C" int yh_run(const yh_op *ops, int n, void *stream, int *failed) {
+extern "C" int yh_run(yh_context *ctx, const yh_op *ops, int n, void *stream, int *failed) {
     YH_REQUIRE(ops || n == 0, "yh_run: null op list");
     hipStream_t mainst = (hipStream_t)stream;
     bool forked = false;
+    int rc = 0, fail_at = -1;
+    auto hip = [&](hipError_t e, const char *what) {           // a failing runtime call on the lane plumbing
+        if (e == hipSuccess) return 0;
+        yh_set_error("yh_run: %s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    };
     for (int k = 0; k < n; ++k) {
         const int kind = ops[k].kind;
-        if (kind == YH_OP_FORK || kind == YH_OP_JOIN) {      // explicit lane synchronisation points
-            if (!side_ready()) continue;                       // overlap disabled: everything runs in list order on `stream`
+        const bool sync_op = kind == YH_OP_FORK || kind == YH_OP_JOIN;
+        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT ||
+                                kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_COLSUM);
+        int sr = 0;
+        if (sync_op || auto_side || ops[k].lane == 1) sr = side_ready(ctx);
+        if (sr < 0) {
+            rc = sr;
+        } else if (sync_op) {                                  // explicit lane synchronisation points
+            if (!sr) continue;                                 // overlap disabled: everything runs in list order on `stream`
             if (kind == YH_OP_FORK) {                          // side lane may proceed past everything enqueued on main so far
-                YH_HIP(hipEventRecord(g_fork, mainst));
-                YH_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+                rc = hip(hipEventRecord(ctx->fork, mainst), "fork record");
+                if (!rc) rc = hip(hipStreamWaitEvent(ctx->side, ctx->fork, 0), "fork wait");
                 forked = true;
             } else if (forked) {                               // main waits for everything enqueued on the side lane so far
-                YH_HIP(hipEventRecord(g_join, g_side));
-                YH_HIP(hipStreamWaitEvent(mainst, g_join, 0));
+                rc = hip(hipEventRecord(ctx->join, ctx->side), "join record");
+                if (!rc) rc = hip(hipStreamWaitEvent(mainst, ctx->join, 0), "join wait");
                 forked = false;
             }
-            continue;
-        }
-        const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT || kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_COLSUM);
-        const bool side = (auto_side || ops[k].lane == 1) && side_ready();
-        int rc;
-        if (side) {
+        } else if (sr == 1) {
             if (auto_side) {     // weight-gradient work: fork right here, after the op that produced dY
-                YH_HIP(hipEventRecord(g_fork, mainst));
-                YH_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
+                rc = hip(hipEventRecord(ctx->fork, mainst), "fork record");
+                if (!rc) rc = hip(hipStreamWaitEvent(ctx->side, ctx->fork, 0), "fork wait");
             }
-            rc = run_one(ops[k], (void *)g_side);
             forked = true;
+            if (!rc) rc = run_one(ops[k], (void *)ctx->side);
         } else {
             rc = run_one(ops[k], stream);
         }
         if (rc) {
-            if (failed) *failed = k;
-            return rc;
+            fail_at = k;
+            break;
         }
     }
-    if (forked) {
-        YH_HIP(hipEventRecord(g_join, g_side));
-        YH_HIP(hipStreamWaitEvent(mainst, g_join, 0));
+    if (rc && failed) *failed = fail_at;
+    // join the side lane on success AND on failure: the caller's stream order must cover everything this call launched
+    if (forked && ctx && ctx->side) {
+        hipError_t e = hipEventRecord(ctx->join, ctx->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(mainst, ctx->join, 0);
+        if (e != hipSuccess && !rc) rc = hip(e, "joining the side lane");
     }
-    return 0;
+    return rc;
 }

@@ -7,6 +7,8 @@
 #include "../../include/yolohip.h"
 
 void yh_set_error(const char *fmt, ...);
+// opt a kernel into `bytes` of dynamic LDS on the current device (api.hip: mutex-guarded (device, kernel) table)
+int yh_ensure_dyn_smem(const void *fn, size_t bytes);
 
 #define YH_REQUIRE(cond, ...)                                  \
     do {                                                       \

@@ -325,12 +325,8 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
 template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT>
 int launch_cfg(GatherGemmSet gs, hipStream_t st) {
     constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 27 * sizeof(int);
-    static bool attr_set = false;
     auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC, NCLS, MT>;
-    if (!attr_set) {
-        YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    if (int rc = yh_ensure_dyn_smem((const void *)kern, smem)) return rc;
     int maxblk = 0;
     for (int c = 0; c < NCLS; ++c) {
         GatherGemm &g = gs.c[c];

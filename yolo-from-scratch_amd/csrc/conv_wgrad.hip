@@ -309,12 +309,8 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
 
 template <int NT, int XL, int DL, int MT>
 int launch_wgrad_cfg(const Plan &pl, hipStream_t st) {
-    static size_t attr = 0;
     auto kern = wgrad_kernel<NT, XL, DL, MT>;
-    if (pl.smem > attr) {
-        YH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.smem));
-        attr = pl.smem;
-    }
+    if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
     hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.ntiles), dim3(256), pl.smem, st, pl.g);
     YH_CHECK_LAUNCH("wgrad");
     return 0;

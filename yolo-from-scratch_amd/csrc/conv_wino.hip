@@ -41,7 +41,8 @@ struct Wino {
 };
 
 constexpr int ZPAD = 2048;      // padding pixels read zeros from here (K <= ZPAD)
-__device__ float wino_zeros[ZPAD + 8];
+// read-only: never written by any kernel or by the host (zero-initialised image in the code object, one per device)
+__device__ const float wino_zeros[ZPAD + 8] = {};
 
 __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
@@ -517,11 +518,7 @@ int launch_nt(Wino &g, hipStream_t st) {
     constexpr int BNW = 32 * NT;
     g.ncol = cdiv(g.N, BNW);
     constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        YH_HIP(hipFuncSetAttribute((const void *)wino_kernel<NT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    if (int rc = yh_ensure_dyn_smem((const void *)wino_kernel<NT, PIPE>, smem)) return rc;
     hipLaunchKernelGGL((wino_kernel<NT, PIPE>), dim3(cdiv(g.ntiles, TPB) * g.ncol), dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("wino");
     return 0;

@@ -373,11 +373,7 @@ extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *cl
     hipStream_t st = (hipStream_t)stream;
     int n = pow2_ge(cap);
     size_t lds = (size_t)(n < kSortLds ? n : kSortLds) * 8;
-    static size_t attr = 0;
-    if (lds > attr) {
-        YH_HIP(hipFuncSetAttribute((const void *)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
-    }
+    if (int rc = yh_ensure_dyn_smem((const void *)nms_sort_kernel, lds)) return rc;
     hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(kNmsThreads), lds, st, a);
     YH_CHECK_LAUNCH("nms_sort");
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.W, a.W), dim3(64), 0, st, a);

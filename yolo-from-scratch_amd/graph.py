@@ -107,6 +107,7 @@ class ConvRec:
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
+    conv: Optional[torch.nn.Conv2d] = None  # the parameter container (staleness checks look the parameters up again)
 
 
 @dataclass
@@ -137,6 +138,8 @@ class Plan:
         self.lane = 0                      # lane given to records traced from now on (see side_lane())
         self.fwd_ops = self.bwd_ops = None
         self.param_ptrs: List[int] = []
+        self._sig_holders = None
+        self._grad_of = None
 
     # ---- tracing API used by the modules ------------------------------------------------------
     def new_buffer(self, B, H, W, C, name="act") -> Buffer:
@@ -166,7 +169,7 @@ class Plan:
         if residual is not None and (residual.H, residual.W, residual.C) != (Ho, Wo, cout):
             raise ValueError("residual shape mismatch")
         self.recs.append(ConvRec(x, out, conv.weight, conv.bias, bn, k, s, residual, upsample, cin=x.C, cout=cout,
-                                 Ho=Ho, Wo=Wo, lane=self.lane))
+                                 Ho=Ho, Wo=Wo, lane=self.lane, conv=conv))
         return out
 
     # independent sub-graphs: `with plan.side_lane():` traces the enclosed layers onto the side stream;
@@ -411,7 +414,8 @@ class Plan:
         self.fwd_ops = _pack(fwd)
         self.bwd_ops = _pack(self._lower_backward(grad_of, keep)) if self.training else None
         self._keep = keep
-        self.param_ptrs = [p.data_ptr() for p in self.params()]
+        self._grad_of = grad_of
+        self.param_ptrs = self._signature()
 
     def _grad_target(self, v: View) -> Tuple[int, int]:
         """Pointer into the gradient tensor of `v` and whether the op must accumulate."""
@@ -564,11 +568,51 @@ class Plan:
         self.bn_epilogue_layers = sum(len(e) for e in tables.values())
 
     # ---- execution ----------------------------------------------------------------------------
+    def _signature(self) -> List[int]:
+        """Every device address the op lists bake in that the plan does not own: parameters, BatchNorm buffers
+        (running statistics, num_batches_tracked) and the gradient destinations."""
+        if self._sig_holders is None:       # (module, attribute) pairs: `bn.running_mean = t` / `p.data = t` must be seen
+            hold, seen = [], set()
+            for r in self.recs:
+                if not isinstance(r, ConvRec):
+                    continue
+                if id(r.conv) not in seen:
+                    seen.add(id(r.conv))
+                    hold += [(r.conv, "weight"), (r.conv, "bias")]
+                if r.bn is not None and id(r.bn) not in seen:
+                    seen.add(id(r.bn))
+                    hold += [(r.bn, "weight"), (r.bn, "bias"), (r.bn, "running_mean"), (r.bn, "running_var"),
+                             (r.bn, "num_batches_tracked")]
+            self._sig_holders = hold
+        sig: List[int] = []
+        for obj, attr in self._sig_holders:
+            t = getattr(obj, attr)
+            if t is None:
+                sig.append(0)
+                continue
+            sig.append(t.data_ptr())
+            if self._grad_of:
+                g = self._grad_of.get(id(t))
+                sig.append(g.data_ptr() if g is not None else 0)
+        return sig
+
     def params_moved(self) -> bool:
-        return [p.data_ptr() for p in self.params()] != self.param_ptrs
+        """True when a parameter, BatchNorm buffer or gradient destination no longer lives at the address the op
+        lists hold (HipTrainer moved the parameters into its flat buffer, load_state_dict(assign=True), a
+        reassigned running_mean, ...): the plan must be re-traced, a captured hipGraph re-captured."""
+        return self._signature() != self.param_ptrs
+
+    def _ctx(self):
+        """This thread's execution context for the plan's device (the C side refuses a context on a foreign device)."""
+        return L.context_for(self.device.index if self.device.index is not None else torch.cuda.current_device())
+
+    def _on_device(self):
+        dev = self.device.index
+        return torch.cuda.device(dev) if dev is not None and torch.cuda.current_device() != dev else _NullCtx()
 
     def run_forward(self, stream: int):
-        L.run_ops(self.fwd_ops[0], self.fwd_ops[1], stream)
+        with self._on_device():
+            L.run_ops(self.fwd_ops[0], self.fwd_ops[1], stream, self._ctx())
         self.generation += 1
 
     def run_backward(self, stream: int, begin: int = 0, end: Optional[int] = None):
@@ -576,7 +620,17 @@ class Plan:
         arr, n = self.bwd_ops
         end = n if end is None else end
         if end > begin:
-            L.run_ops(ctypes.cast(ctypes.byref(arr, begin * ctypes.sizeof(L.YhOp)), ctypes.POINTER(L.YhOp)), end - begin, stream)
+            with self._on_device():
+                L.run_ops(ctypes.cast(ctypes.byref(arr, begin * ctypes.sizeof(L.YhOp)), ctypes.POINTER(L.YhOp)), end - begin,
+                          stream, self._ctx())
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 def _addr(x) -> Optional[int]:

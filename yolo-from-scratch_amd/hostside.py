@@ -259,7 +259,7 @@ def load_checkpoint(path, num_classes=None, device="cpu"):
     path).  Reference-written files carry stride-0 expanded grid_* buffers (which makes the
     reference's own load_state_dict fail on torch 2.x): here they are copied into contiguous buffers."""
     from .modules import YOLO
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)      # plain tensors + ints/floats only
     nc = num_classes if num_classes is not None else ckpt.get("num_classes", 1)
     model = YOLO(num_classes=nc, img_size=ckpt.get("img_size", 640), width_mult=ckpt.get("width_mult", 0.50),
                  depth_mult=ckpt.get("depth_mult", 0.33))

@@ -21,7 +21,9 @@ class Detector:
     """Fixed-capacity device buffers + the two kernels of the post-process.  Everything stays on the
     device until `fetch`; capacity = every cell of the three grids, so nothing is ever truncated."""
 
-    def __init__(self, grids: Sequence[int], num_classes: int, device):
+    def __init__(self, grids: Sequence[int], num_classes: int, device, nms_workspace: torch.Tensor = None):
+        """nms_workspace: a suppression-matrix scratch shared with other Detectors whose calls run in order on
+        one stream (predict_batch): it is cap * ceil(cap/64) * 8 bytes (79 MB at 640x640, 1.27 GB at 1280)."""
         L.lib()
         self.grids, self.nc, self.device = [int(g) for g in grids], int(num_classes), device
         self.cap = sum(3 * g * g for g in self.grids)
@@ -33,7 +35,11 @@ class Detector:
         self.keep = torch.empty(self.cap, **i32)
         self.nkeep = torch.zeros(1, **i32)
         self.ws_c = torch.empty(int(L.lib().yh_candidates_ws(L.int3(self.grids))) + 4, **i32)
-        self.ws_n = torch.empty(int(L.lib().yh_nms_ws(self.cap)) + 256, device=device, dtype=torch.uint8)
+        need = int(L.lib().yh_nms_ws(self.cap)) + 256
+        if nms_workspace is not None and (nms_workspace.numel() < need or nms_workspace.device != torch.device(device)
+                                          or nms_workspace.dtype != torch.uint8):
+            raise ValueError("nms_workspace too small / wrong device or dtype")
+        self.ws_n = nms_workspace if nms_workspace is not None else torch.empty(need, device=device, dtype=torch.uint8)
 
     def candidates(self, preds: Sequence[torch.Tensor], anchors_list, img_size, conf_threshold, pad_left=0.0,
                    pad_top=0.0, scale=1.0, letterbox_dev: torch.Tensor = None):
@@ -127,7 +133,8 @@ def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_
     grids = [p.shape[1] for p in preds]
     dets = getattr(model, "_detectors", None)
     if dets is None or len(dets) < len(xs) or dets[0].grids != grids or dets[0].nc != num_classes or dets[0].device != preds[0].device:
-        dets = [Detector(grids, num_classes, preds[0].device) for _ in xs]
+        first = Detector(grids, num_classes, preds[0].device)      # per image: boxes/scores/keep; ONE suppression matrix
+        dets = [first] + [Detector(grids, num_classes, preds[0].device, nms_workspace=first.ws_n) for _ in xs[1:]]
         model._detectors = dets
     for b, (pad_left, pad_top, scale) in enumerate(meta):
         dets[b].candidates([p[b:b + 1] for p in preds], model.anchors, S, conf_threshold, pad_left, pad_top, scale)
@@ -150,12 +157,23 @@ class InferenceSession:
         self.conf, self.iou = float(conf_threshold), float(iou_threshold)
         self.x = torch.zeros(1, 3, self.S, self.S, device=self.device)
         self.lb = torch.tensor([0.0, 0.0, 1.0], device=self.device)
+        self.use_graph = bool(use_graph)
+        self.det = None
+        self._build()
+
+    def _build(self):
+        """Trace the eval plan and (re)capture the hipGraph.  Called again by run() when a parameter, BatchNorm
+        buffer or the model's mode moved under the plan (HipTrainer adopting the parameters, load_state_dict(assign=True),
+        ...): the op lists and the captured graph hold raw device addresses."""
+        model = self.model.eval()
         with torch.no_grad():
             self.plan = model._plan_for(self.x)
         self.heads = [v for v, _ in self.plan.outputs]
-        self.det = Detector([v.H for v in self.heads], self.nc, self.device)
+        grids = [v.H for v in self.heads]
+        if self.det is None or self.det.grids != grids:
+            self.det = Detector(grids, self.nc, self.device)
         self.graph = None
-        if use_graph:
+        if self.use_graph:
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
@@ -176,6 +194,8 @@ class InferenceSession:
 
     def run(self, img: torch.Tensor, pad_left=0.0, pad_top=0.0, scale=1.0, fetch=True):
         """img: (1,3,S,S) or (3,S,S) float tensor (host or device).  Returns the detections list."""
+        if self.plan.params_moved():
+            self._build()
         self.x.copy_(img.reshape(self.x.shape), non_blocking=True)
         self.lb.copy_(torch.tensor([pad_left, pad_top, scale], dtype=torch.float32), non_blocking=True)
         if self.graph is not None:

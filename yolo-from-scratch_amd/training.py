@@ -24,6 +24,24 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+def check_targets(targets, shapes, device):
+    """The fused step hands raw device pointers to yh_yolo_loss with the batch / grid sizes of the plan, so the targets
+    must match them exactly -- the reference raises a shape error in its loss for the same mistakes (train.py:806-830)."""
+    if len(targets) != len(shapes):
+        raise ValueError(f"expected {len(shapes)} target tensors (one per scale), got {len(targets)}")
+    out = []
+    for s, (t, want) in enumerate(zip(targets, shapes)):
+        if not isinstance(t, torch.Tensor) or t.device.type != "cuda" or t.device != torch.device(device):
+            raise ValueError(f"target[{s}] must live on {device} (got {getattr(t, 'device', type(t))}); no CPU fallback")
+        if t.dtype != torch.float32:
+            raise ValueError(f"target[{s}] must be float32, got {t.dtype}")
+        if tuple(t.shape) != tuple(want):
+            raise ValueError(f"target[{s}] has shape {tuple(t.shape)}, the step expects {tuple(want)} "
+                             "(batch, grid, grid, 3, 5 + num_classes of the model / input batch)")
+        out.append(t.contiguous())
+    return out
+
+
 class GradBuckets:
     """Data-parallel gradient exchange over a flat gradient buffer (torch.distributed only: RCCL on the
     GPUs, gloo in the CPU tests).  The buffer is cut into contiguous buckets (parameter registration
@@ -128,11 +146,12 @@ class HipTrainer:
             grids = [v.H for v, _ in plan.outputs]
             self._loss_ws = torch.empty(int(L.lib().yh_loss_ws(L.int3(grids), plan.B)) + 8, device=self.device,
                                         dtype=torch.float32)
-        model._load_input(plan, imgs)
-        plan.run_forward(st)
         heads = [v for v, _ in plan.outputs]
         nc = model.num_classes
-        run_loss_kernel([v.buf.data for v in heads], [t.contiguous() for t in targets], [v.buf.grad for v in heads],
+        targets = check_targets(targets, [(plan.B, v.H, v.W, 3, 5 + nc) for v in heads], self.device)
+        model._load_input(plan, imgs)
+        plan.run_forward(st)
+        run_loss_kernel([v.buf.data for v in heads], targets, [v.buf.grad for v in heads],
                         _anchors18(model.anchors), [v.H for v in heads], plan.B, nc, None, None, self.loss_out,
                         self._loss_ws, st)
         begin = 0
