@@ -126,6 +126,22 @@ def cpu_baseline(batch=8, steps=3):
             "sample": f"median of {steps} full training steps at batch {batch} (of {BATCH}) after 1 warm-up, same model/inputs"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` as a bare command: start N fresh rank processes through torch.distributed.run (one per
+    GPU, rendezvous on 127.0.0.1) and relay their output; this parent never initialises the GPU and never execs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +151,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path with several ranks sharing one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)          # before anything touches the GPU in this process
 
     import torch.distributed as dist
     import yolo_from_scratch_amd as y
