@@ -242,6 +242,12 @@ int yh_yolo_loss(const float *const pred[3], const float *const target[3], float
                  const float *anchors, const int grid[3], int B, int nc, float loss_img_size, const float *loss_w,
                  const float *grad_w, float *out, float *ws, void *stream);
 int64_t yh_loss_ws(const int grid[3], int B);
+/* The same with a typed gradient: dpred_bf16 != 0 writes bf16 (the bf16 path's head gradient); dpred_ld[s] = elements
+ * per PIXEL of dpred[s] (3 anchors x (5+nc), possibly padded to a multiple of 8 so that the backward GEMMs can read it
+ * in 16-byte pieces; the padding is zeroed), NULL or 0 = contiguous. */
+int yh_yolo_loss_ex(const float *const pred[3], const float *const target[3], void *const dpred[3], int dpred_bf16,
+                    const int dpred_ld[3], const float *anchors, const int grid[3], int B, int nc, float loss_img_size,
+                    const float *loss_w, const float *grad_w, float *out, float *ws, void *stream);
 /* eval_epoch's detection metric (train.py:990-1024): counts[0..3) += TP, FP, FN over all cells of the three
  * scales -- same cell, same anchor; sigmoid(obj) > conf_thr vs target obj > conf_thr; a matched pair is a TP when
  * compute_box_iou (centre format, eps 1e-6) > iou_thr, else an FP.  counts is a DEVICE int64[3] the caller zeroes
@@ -295,6 +301,48 @@ int64_t yh_sqnorm_ws(int64_t n);
 int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, double lr, double beta1, double beta2,
                  double eps, int step, float max_norm, const float *norm, float grad_scale, void *stream);
 
+/* ---- bf16 path (BASELINE configs 3-4: "bf16 MFMA implicit-GEMM conv") --------------------------------------------- */
+/* Activations, activation gradients and the per-step weight packs are bf16 (void * below = bf16 elements, ld counted in
+ * elements); accumulators, bias, BatchNorm statistics / coefficients, the loss and every parameter gradient are fp32;
+ * the master weights stay fp32 OIHW.  Convolutions run on v_mfma_f32_32x32x16_bf16; channel counts feeding a GEMM's K
+ * axis and every ld must be multiples of 8 (16-byte pieces), views 16-byte aligned.
+ * replaces: the same call sites as the fp32 entry points of the same name (train.py:253-265, 401-466, 913). */
+/* OIHW fp32 -> bf16 packs for n convolutions in one launch.  `table`: DEVICE array of 56-byte records
+ * { const float *oihw; bf16 *wf, *wb; int32 Cout, Cin, k*k, cin_pad, ldf, ldb, koff_b, kpad_b }:
+ * wf[tap][cin_pad/8][ldf][8] (forward: K = cin_pad, N = Cout), wb[tap][kpad_b/8][ldb][8] (backward-data: K rows
+ * [koff_b, koff_b + Cout) of a matrix with kpad_b rows -- two C3 sibling convs stack into one --, N = Cin); either
+ * destination may be NULL; rows / columns beyond the real channel counts are zero. */
+int yh_bf16_pack_multi(const void *table, int n, void *stream);
+/* y = conv(x, wf) (+ bias); y is bf16, or fp32 when y_f32 (head outputs feeding the fp32 loss).  bn_partials:
+ * [yh_bf16_conv_blocks(M)][2][Cout] sums / sums of squares of the STORED (bf16-rounded) values, or NULL. */
+int yh_bf16_conv_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, int y_f32,
+                     float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
+int yh_bf16_conv_blocks(int64_t M);
+/* dx (+)= conv_transpose(dy, wb); Cout = K rows of wb (a multiple of 8: pad dY with zeros).  dy2 != NULL: pointwise
+ * only, K rows [0, kcout1) come from dy, [kcout1, Cout) from dy2 (same ld): the fused C3 sibling pair. */
+int yh_bf16_conv_bwd_data(const void *dy, int lddy, const void *dy2, int kcout1, const void *wb, int ldwb, void *dx, int lddx,
+                          int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int accumulate, void *stream);
+/* dw (OIHW fp32, cin_real input channels) = sum_pixels x * dy; deterministic (fp32 slabs in ws, fixed-order sum).
+ * dY must be readable up to roundup8(Cout) channels per pixel. */
+int yh_bf16_conv_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                            int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k, int s, void *stream);
+int64_t yh_bf16_conv_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s);
+/* bf16 forms of the HBM-bound passes (same arguments as the fp32 entry points; compute in fp32) */
+int yh_bf16_nchw_to_nhwc(const float *src, void *dst, int B, int C, int H, int W, int ld, int cpad, void *stream);
+int yh_bf16_u8hwc_to_nhwc(const uint8_t *src, void *dst, int B, int H, int W, int C, int ld, int cpad, void *stream);
+int yh_bf16_nhwc_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ld, int accumulate, void *stream);
+int yh_bf16_colsum(const void *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream);
+int yh_bf16_bn_silu_fwd(const void *y, int ldy, const float *coef, const void *residual, int ldr, void *out, int ldo, int64_t M,
+                        int C, int H, int W, int upsample, void *stream);
+int yh_bf16_bn_silu_bwd_reduce(const void *da, int ldda, const void *y, int ldy, const float *coef, float *partials, int64_t M,
+                               int C, int H, int W, int upsample, void *stream);
+int yh_bf16_bn_silu_bwd_apply(const void *da, int ldda, const void *y, int ldy, const float *coef, const float *partials,
+                              int nblk, const float *gamma, float *dgamma, float *dbeta, void *dy, int lddy, void *dres,
+                              int lddres, int res_accumulate, int64_t M, int C, int H, int W, int upsample, void *stream);
+int yh_bf16_maxpool5_fwd(const void *x, int ldx, void *y, int ldy, uint8_t *argmax, int B, int H, int W, int C, void *stream);
+int yh_bf16_maxpool5_bwd(const void *dy, int lddy, const uint8_t *argmax, void *dx, int lddx, int B, int H, int W, int C,
+                         void *stream);
+
 /* ---- small utilities (stream-ordered) --------------------------------------------------------------- */
 int yh_memset(void *p, int value, int64_t bytes, void *stream);
 /* *p += v on the device (BatchNorm2d.num_batches_tracked). */
@@ -321,7 +369,11 @@ enum {
     YH_OP_JOIN,   /* caller's stream waits for everything issued on the side lane so far */
     YH_OP_WINO_WEIGHTS_MULTI, YH_OP_CONV_WINO_FWD, YH_OP_CONV_WINO_BWD_DATA, YH_OP_CONV_WINO_BWD_WEIGHT,
     YH_OP_CONV_PW_BWD_WEIGHT, YH_OP_PW_PACK_MULTI, YH_OP_CONV_PW_FWD, YH_OP_CONV_PW_BWD_DATA,
-    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M, YH_OP_CONV_PW_FWD2, YH_OP_NOP
+    YH_OP_CONV_STEM_FWD, YH_OP_PACK_WEIGHTS_S2M, YH_OP_CONV_BWD_DATA_S2M, YH_OP_CONV_PW_FWD2, YH_OP_NOP,
+    /* bf16 path: argument slots as in the fp32 op of the same name unless noted in api.hip */
+    YH_OP_BF16_PACK_MULTI, YH_OP_BF16_CONV_FWD, YH_OP_BF16_CONV_BWD_DATA, YH_OP_BF16_CONV_BWD_WEIGHT, YH_OP_BF16_COLSUM,
+    YH_OP_BF16_BN_SILU_FWD, YH_OP_BF16_BN_SILU_BWD_REDUCE, YH_OP_BF16_BN_SILU_BWD_APPLY, YH_OP_BF16_MAXPOOL5_FWD,
+    YH_OP_BF16_MAXPOOL5_BWD
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

@@ -29,7 +29,9 @@ class YhOp(C.Structure):
  OP_MAXPOOL5_FWD, OP_MAXPOOL5_BWD, OP_MEMSET, OP_ADD_INT64, OP_PACK_WEIGHTS_MULTI, OP_PACK_FOLD_MULTI,
  OP_CONV_FWD_FUSED, OP_CONV_BWD_DATA_PAIR, OP_FORK, OP_JOIN, OP_WINO_WEIGHTS_MULTI, OP_CONV_WINO_FWD,
  OP_CONV_WINO_BWD_DATA, OP_CONV_WINO_BWD_WEIGHT, OP_CONV_PW_BWD_WEIGHT, OP_PW_PACK_MULTI, OP_CONV_PW_FWD,
- OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M, OP_CONV_PW_FWD2, OP_NOP) = range(1, 36)
+ OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M, OP_CONV_PW_FWD2, OP_NOP,
+ OP_BF16_PACK_MULTI, OP_BF16_CONV_FWD, OP_BF16_CONV_BWD_DATA, OP_BF16_CONV_BWD_WEIGHT, OP_BF16_COLSUM, OP_BF16_BN_SILU_FWD,
+ OP_BF16_BN_SILU_BWD_REDUCE, OP_BF16_BN_SILU_BWD_APPLY, OP_BF16_MAXPOOL5_FWD, OP_BF16_MAXPOOL5_BWD) = range(1, 46)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -88,6 +90,24 @@ _SIGS = {
     "yh_maxpool5_bwd": (i32, [c_fp, i32, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_yolo_loss": (i32, [_PP, _PP, _PP, C.POINTER(f32), _IP, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp, c_fp]),
     "yh_loss_ws": (i64, [_IP, i32]),
+    "yh_yolo_loss_ex": (i32, [_PP, _PP, _PP, i32, _IP, C.POINTER(f32), _IP, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp,
+                              c_fp]),
+    "yh_bf16_pack_multi": (i32, [c_fp, i32, c_fp]),
+    "yh_bf16_conv_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_blocks": (i32, [i64]),
+    "yh_bf16_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),
+    "yh_bf16_nchw_to_nhwc": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_u8hwc_to_nhwc": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_nhwc_to_nchw": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_colsum": (i32, [c_fp, i32, i64, i32, c_fp, c_fp, c_fp]),
+    "yh_bf16_bn_silu_fwd": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_bn_silu_bwd_reduce": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_bn_silu_bwd_apply": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32,
+                                        i64, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_maxpool5_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_maxpool5_bwd": (i32, [c_fp, i32, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_eval_counts": (i32, [_PP, _PP, C.POINTER(f32), _IP, i32, i32, f32, f32, f32, c_fp, c_fp]),
     "yh_decode": (i32, [c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),
     "yh_decode_bwd": (i32, [c_fp, c_fp, c_fp, C.POINTER(f32), i32, i32, i32, i32, f32, c_fp]),

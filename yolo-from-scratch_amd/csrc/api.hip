@@ -108,6 +108,33 @@ static int run_one(const yh_op &o, void *st) {
                                           (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], p[4], i[10], st);
         case YH_OP_NOP:
             return 0;
+        // ---- bf16 path ----------------------------------------------------------------------------------------------
+        case YH_OP_BF16_PACK_MULTI:
+            return yh_bf16_pack_multi(p[0], i[0], st);
+        case YH_OP_BF16_CONV_FWD:           /* slots of YH_OP_CONV_FWD; i[10] = output is fp32 */
+            return yh_bf16_conv_fwd(p[0], i[0], p[1], i[1], (const float *)p[2], p[3], i[2], i[10], (float *)p[4], i[3], i[4], i[5],
+                                    i[6], i[7], i[8], i[9], st);
+        case YH_OP_BF16_CONV_BWD_DATA:      /* slots of YH_OP_CONV_BWD_DATA; p[3] / i[11]: second source dy2 / its first K row */
+            return yh_bf16_conv_bwd_data(p[0], i[0], p[3], i[11], p[1], i[1], p[2], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9],
+                                         i[10], st);
+        case YH_OP_BF16_CONV_BWD_WEIGHT:    /* slots of YH_OP_CONV_BWD_WEIGHT */
+            return yh_bf16_conv_bwd_weight(p[0], i[0], p[1], i[1], (float *)p[2], (float *)p[3], o.l[0], i[2], i[3], i[4], i[5],
+                                           i[6], i[7], i[8], i[9], st);
+        case YH_OP_BF16_COLSUM:
+            return yh_bf16_colsum(p[0], i[0], o.l[0], i[1], (float *)p[1], (float *)p[2], st);
+        case YH_OP_BF16_BN_SILU_FWD:
+            return yh_bf16_bn_silu_fwd(p[0], i[0], (const float *)p[1], p[2], i[1], p[3], i[2], o.l[0], i[3], i[4], i[5], i[6], st);
+        case YH_OP_BF16_BN_SILU_BWD_REDUCE:
+            return yh_bf16_bn_silu_bwd_reduce(p[0], i[0], p[1], i[1], (const float *)p[2], (float *)p[3], o.l[0], i[2], i[3], i[4],
+                                              i[5], st);
+        case YH_OP_BF16_BN_SILU_BWD_APPLY:
+            return yh_bf16_bn_silu_bwd_apply(p[0], i[0], p[1], i[1], (const float *)p[2], (const float *)p[3], i[2],
+                                             (const float *)p[4], (float *)p[5], (float *)p[6], p[7], i[3], p[8], i[4], i[5], o.l[0],
+                                             i[6], i[7], i[8], i[9], st);
+        case YH_OP_BF16_MAXPOOL5_FWD:
+            return yh_bf16_maxpool5_fwd(p[0], i[0], p[1], i[1], (uint8_t *)p[2], i[2], i[3], i[4], i[5], st);
+        case YH_OP_BF16_MAXPOOL5_BWD:
+            return yh_bf16_maxpool5_bwd(p[0], i[0], (const uint8_t *)p[1], p[2], i[1], i[2], i[3], i[4], i[5], st);
         case YH_OP_CONV_BWD_DATA_PAIR:
             return yh_conv_bwd_data_pair((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
                                          (float *)p[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
@@ -261,7 +288,8 @@ extern "C" int yh_run(yh_context *ctx, const yh_op *ops, int n, void *stream, in
         const int kind = ops[k].kind;
         const bool sync_op = kind == YH_OP_FORK || kind == YH_OP_JOIN;
         const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT ||
-                                kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_COLSUM);
+                                kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_COLSUM || kind == YH_OP_BF16_CONV_BWD_WEIGHT ||
+                                kind == YH_OP_BF16_COLSUM);
         int sr = 0;
         if (sync_op || auto_side || ops[k].lane == 1) sr = side_ready(ctx);
         if (sr < 0) {

@@ -1,0 +1,764 @@
+// bf16 convolution path (BASELINE configs 3-4): implicit GEMM on v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+// Activations, their gradients and the per-step weight packs are bf16 in HBM; accumulation, bias, BatchNorm statistics
+// and the weight gradients are fp32; the master weights stay fp32 (the packs are rebuilt from them every step).
+// At bf16 MFMA rates this network is HBM-bound in every layer (the whole forward is capped at ~27 % of the
+// bf16 MFMA peak by activation traffic alone), so the design goals are bytes, not FLOPs: 16-byte loads along the
+// channel axis, every activation read once per consumer, 16-byte stores through an LDS transpose of the accumulators.
+//
+//  * bf16_gemm_kernel   forward and backward-data of every conv shape (k 1/3, stride 1/2, the stride-2 parity classes
+//                       and the fused C3 sibling pair) as ONE gather GEMM: out[p][n] (+)= sum_{tap,c} in[g(p,tap)][c] w[tap][c][n]
+//  * bf16_wgrad_kernel  dW[tap][ci][co] = sum_p x[g(p,tap)][ci] dy[p][co]: both operands have the reduction index
+//                       (pixels) as their slow axis in NHWC, so the MFMA fragments (8 consecutive k per lane) are read
+//                       from LDS with the transposing ds_read_b64_tr_b16; fp32 slabs + fixed-order reduction (bitwise
+//                       reproducible), OIHW fp32 gradient.
+//
+// MFMA operand maps (cdna guide section 3): v_mfma_f32_32x32x16_bf16, lane l (r = l & 31, h = l >> 5) holds
+// A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7; D register q of lane l = D[(q & 3) + 8 (q >> 2) + 4h][col r].
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BK = 64;                 // k per chunk = 8 octets of 8 bf16 (16 bytes)
+constexpr int A_STRIDE = BK * 2 + 16;  // bytes per A-tile row: 144 -> the 16 rows of a ds_read_b128 lane group hit 16 distinct bank quads
+
+struct BfGemm {
+    const bf16 *in, *in2;   // in2: optional second source for k >= ksplit (pointwise only: the C3 sibling pair)
+    int ksplit;
+    const bf16 *w;          // [tap][Cin/8][ldw][8]
+    const float *bias;
+    void *out;              // bf16 (out_f32 == 0) or float
+    float *stats;           // [cdiv(M,BM)][2][N] per-workgroup column sums / sums of squares of the STORED (rounded) values
+    int Hi, Wi, ldi, Cin;   // Cin = k per tap, a multiple of 8
+    int ldw;                // 16-byte entries per octet row of w (>= N)
+    int Ho_f, Wo_f, ldo, N;
+    int B, Yo, Xo, M;
+    int osy, osx, ooy, oox, sy, sx;
+    int nTaps, Ktot;
+    int accumulate, dense, out_f32;
+    int nblk_n;
+    unsigned cin_magic, xo_magic, yo_magic;
+    int xo_shift, yo_shift;
+    int tap_dy[9], tap_dx[9], tap_w[9];
+};
+struct BfGemmSet {
+    BfGemm c[4];
+};
+
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
+    return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
+}
+
+__device__ __forceinline__ int mfma_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
+
+template <int BM, int BN, int WM, int WN, int NCLS>
+__global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
+    const BfGemm &g = gs.c[NCLS == 1 ? 0 : blockIdx.y];
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AROWS = BM / 32;           // 16-byte A loads per thread per chunk
+    constexpr int BPASS = (8 * BN + 255) / 256;
+    constexpr int C_STRIDE = BN * 2 + 16;    // bytes per row of the epilogue staging tile
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *As = smem;                              // [2][BM][A_STRIDE]
+    unsigned char *Bs = smem + 2 * BM * A_STRIDE;          // [2][8][BN][16]
+    int *tapt = (int *)(Bs + 2 * 8 * BN * 16);             // [3][9]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    // XCD-aware bijective remap (guide T1): each XCD walks a contiguous range of tiles, n-tiles of one m-tile adjacent
+    const int nwg = ((g.M + BM - 1) / BM) * g.nblk_n, orig = blockIdx.x;
+    if (orig >= nwg) return;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int mblk = tile / g.nblk_n, nblk = tile - mblk * g.nblk_n;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    if (t < 9) {
+        tapt[t] = g.tap_dy[t];
+        tapt[9 + t] = g.tap_dx[t];
+        tapt[18 + t] = g.tap_w[t];
+    }
+
+    const int kq = t & 7;
+    int roff[AROWS], riy[AROWS], rix[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        int m = m0 + (t >> 3) + 32 * i;
+        if (m < g.M) {
+            int q = fast_div(m, g.xo_magic, g.xo_shift), x = m - q * g.Xo;
+            int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
+            riy[i] = y * g.sy;
+            rix[i] = x * g.sx;
+            roff[i] = ((b * g.Hi + riy[i]) * g.Wi + rix[i]) * g.ldi;
+        } else {
+            roff[i] = 0;
+            riy[i] = -(1 << 20);
+            rix[i] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int cin8 = g.Cin >> 3;
+    u32x4 ra[AROWS], rb[BPASS];
+    auto load_tiles = [&](int c) {
+        const int k = c * BK + 8 * kq;
+        if (k < g.Ktot) {
+            int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
+            int dy = tapt[tap], dx = tapt[9 + tap];
+            int toff = (dy * g.Wi + dx) * g.ldi + ci;
+            const bf16 *inb = (g.in2 && k >= g.ksplit) ? g.in2 - g.ksplit : g.in;
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                ra[i] = ok ? *(const u32x4 *)(inb + (roff[i] + toff)) : u32x4{0u, 0u, 0u, 0u};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) ra[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int e = t + 256 * p;
+            int o = e / BN, n = n0 + (e - o * BN);
+            int kr = c * BK + 8 * o;
+            if (o < 8 && kr < g.Ktot && n < g.ldw) {
+                int tap = (int)__umulhi((unsigned)kr, g.cin_magic), ci = kr - tap * g.Cin;
+                rb[p] = *(const u32x4 *)(g.w + ((size_t)((tapt[18 + tap] * cin8 + (ci >> 3)) * g.ldw + n) << 3));
+            } else {
+                rb[p] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char *a = As + buf * BM * A_STRIDE;
+        unsigned char *b = Bs + buf * 8 * BN * 16;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) *(u32x4 *)(a + ((t >> 3) + 32 * i) * A_STRIDE + 16 * kq) = ra[i];
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            int e = t + 256 * p;
+            if (e < 8 * BN) *(u32x4 *)(b + e * 16) = rb[p];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nchunks = (g.Ktot + BK - 1) / BK;
+    auto compute = [&](int buf, int kvalid) {
+        const unsigned char *a = As + buf * BM * A_STRIDE + (wm * TM * 32 + lr) * A_STRIDE + 16 * lh;
+        const unsigned char *b = Bs + buf * 8 * BN * 16 + (lh * BN + wn * TN * 32 + lr) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks * 16 >= kvalid) break;
+            bf16x8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *(const bf16x8 *)(a + i * 32 * A_STRIDE + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *(const bf16x8 *)(b + (2 * ks * BN + j * 32) * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // register-staged double buffer: the loads of chunk c+1 are in flight while chunk c is multiplied
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_tiles(c + 1);
+        compute(c & 1, g.Ktot - c * BK);
+        if (c + 1 < nchunks) store_tiles((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------------------
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + wn * TN * 32 + j * 32 + lr;
+        bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
+    const bool staged = !g.out_f32 && (g.N & 7) == 0 && (g.ldo & 7) == 0 && (((uintptr_t)g.out) & 15) == 0;
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+    unsigned char *Cs = smem;              // [BM][C_STRIDE] (the main loop ended with a barrier)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rl = wm * TM * 32 + i * 32 + mfma_row(q, lh);
+            const int m = m0 + rl;
+            if (staged) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cl = wn * TN * 32 + j * 32 + lr;
+                    bf16 hv = (bf16)(acc[i][j][q] + bias_v[j]);
+                    *(bf16 *)(Cs + rl * C_STRIDE + cl * 2) = hv;
+                    if (m < g.M && n0 + cl < g.N) {
+                        float vq = (float)hv;
+                        csum[j] += vq;
+                        csq[j] += vq * vq;
+                    }
+                }
+            } else if (m < g.M) {
+                size_t opix;
+                if (g.dense) {
+                    opix = (size_t)m;
+                } else {
+                    int qq = fast_div(m, g.xo_magic, g.xo_shift), x = m - qq * g.Xo;
+                    int b = fast_div(qq, g.yo_magic, g.yo_shift), y = qq - b * g.Yo;
+                    opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + lr;
+                    if (n < g.N) {
+                        float v = acc[i][j][q] + bias_v[j];
+                        if (g.out_f32) {
+                            float *o = (float *)g.out + opix * g.ldo + n;
+                            if (g.accumulate) v += *o;
+                            *o = v;
+                        } else {
+                            bf16 *o = (bf16 *)g.out + opix * g.ldo + n;
+                            if (g.accumulate) v += (float)*o;
+                            bf16 hv = (bf16)v;
+                            *o = hv;
+                            v = (float)hv;
+                        }
+                        csum[j] += v;
+                        csq[j] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        constexpr int PCS = BN / 8;            // 16-byte pieces per row
+        for (int p = t; p < BM * PCS; p += 256) {
+            const int rl = p / PCS, oc = p - rl * PCS;
+            const int m = m0 + rl, n = n0 + 8 * oc;
+            if (m >= g.M || n >= g.N) continue;
+            size_t opix;
+            if (g.dense) {
+                opix = (size_t)m;
+            } else {
+                int qq = fast_div(m, g.xo_magic, g.xo_shift), x = m - qq * g.Xo;
+                int b = fast_div(qq, g.yo_magic, g.yo_shift), y = qq - b * g.Yo;
+                opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
+            }
+            bf16x8 v = *(const bf16x8 *)(Cs + rl * C_STRIDE + oc * 16);
+            bf16 *o = (bf16 *)g.out + opix * g.ldo + n;
+            if (g.accumulate) {
+                bf16x8 old = *(const bf16x8 *)o;
+                f32x8 s = __builtin_convertvector(v, f32x8) + __builtin_convertvector(old, f32x8);
+                v = __builtin_convertvector(s, bf16x8);
+            }
+            *(bf16x8 *)o = v;
+        }
+    }
+    if (g.stats) {
+        __syncthreads();
+        float *red = (float *)(smem + BM * C_STRIDE);     // [WM][BN][2], behind the staging tile
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) {
+                int col = wn * TN * 32 + j * 32 + lr;
+                red[(wm * BN + col) * 2 + 0] = s;
+                red[(wm * BN + col) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < g.N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s += red[(w * BN + t) * 2 + 0];
+                q += red[(w * BN + t) * 2 + 1];
+            }
+            g.stats[((size_t)mblk * 2 + 0) * g.N + n0 + t] = s;
+            g.stats[((size_t)mblk * 2 + 1) * g.N + n0 + t] = q;
+        }
+    }
+}
+
+void set_magic(unsigned d, unsigned &magic, int &shift) {
+    int l = 0;
+    while ((1u << l) < d) ++l;
+    magic = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    shift = l - 1;
+}
+
+constexpr int GEMM_BM = 128;
+
+template <int BN, int WM, int WN, int NCLS>
+int launch_cfg(BfGemmSet &gs, hipStream_t st) {
+    constexpr int BM = GEMM_BM;
+    constexpr size_t main_b = (size_t)2 * BM * A_STRIDE + 2 * 8 * BN * 16 + 27 * sizeof(int);
+    constexpr size_t epi_b = (size_t)BM * (BN * 2 + 16) + (size_t)WM * BN * 2 * sizeof(float);
+    constexpr size_t smem = main_b > epi_b ? main_b : epi_b;
+    auto kern = bf16_gemm_kernel<BM, BN, WM, WN, NCLS>;
+    if (int rc = yh_ensure_dyn_smem((const void *)kern, smem)) return rc;
+    int maxblk = 0;
+    for (int c = 0; c < NCLS; ++c) {
+        BfGemm &g = gs.c[c];
+        g.nblk_n = cdiv(g.N, BN);
+        g.cin_magic = (unsigned)((1ull << 32) / (unsigned)g.Cin) + 1u;
+        int blk = cdiv(g.M, BM) * g.nblk_n;
+        if (blk > maxblk) maxblk = blk;
+    }
+    hipLaunchKernelGGL(kern, dim3(maxblk, NCLS), dim3(256), smem, st, gs);
+    YH_CHECK_LAUNCH("bf16_gemm");
+    return 0;
+}
+
+template <int NCLS>
+int launch_set(BfGemmSet &gs, hipStream_t st) {
+    for (int c = 0; c < NCLS; ++c) {
+        BfGemm &g = gs.c[c];
+        YH_REQUIRE(g.M > 0 && g.N > 0 && g.Ktot > 0, "bf16_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.Ktot);
+        YH_REQUIRE(g.Cin % 8 == 0 && g.ldi % 8 == 0 && (((uintptr_t)g.in | (uintptr_t)g.in2) & 15) == 0,
+                   "bf16_gemm: input channels (%d) and ld (%d) must be multiples of 8 and the view 16-byte aligned", g.Cin, g.ldi);
+        YH_REQUIRE(g.ldw >= g.N && ((uintptr_t)g.w & 15) == 0, "bf16_gemm: weight pack narrower than N or misaligned");
+        YH_REQUIRE(g.Ktot < 65536 && (int64_t)g.B * g.Hi * g.Wi * g.ldi < (1ll << 31) && (int64_t)g.Ktot * g.ldw < (1ll << 31),
+                   "bf16_gemm: problem exceeds the 32-bit element-offset range");
+        YH_REQUIRE(!g.in2 || (g.ksplit % 8 == 0 && g.nTaps == 1), "bf16_gemm: two-source K needs a pointwise problem and ksplit %% 8 == 0");
+        set_magic((unsigned)g.Xo, g.xo_magic, g.xo_shift);
+        set_magic((unsigned)g.Yo, g.yo_magic, g.yo_shift);
+    }
+    const int N = gs.c[0].N;
+    if (N <= 32) return launch_cfg<32, 4, 1, NCLS>(gs, st);
+    if (N <= 64) return launch_cfg<64, 2, 2, NCLS>(gs, st);
+    return launch_cfg<128, 2, 2, NCLS>(gs, st);
+}
+
+// ---- weight packs -----------------------------------------------------------------------------------------------------
+// forward  Wf[tap][cin_pad/8][ldf][8]: element (tap, ci, n = co)  = w[co][ci][tap]          (K = cin_pad, N = Cout)
+// backward Wb[tap][cout_pad/8][ldb][8]: element (tap, co, n = ci) = w[co][ci][tap]          (K = cout_pad, N = cin_pad)
+// rows / columns past the real channel counts are zero.  koff_b: first K row of this conv inside a stacked backward
+// matrix (the C3 sibling pair), kpad_b: K rows of the whole stacked matrix.
+struct BfPackDesc {
+    const float *w;
+    bf16 *wf, *wb;
+    int Cout, Cin, kk, cin_pad, ldf, ldb, koff_b, kpad_b;
+};
+static_assert(sizeof(BfPackDesc) == 56, "descriptor layout is part of the ABI");
+
+__global__ void bf16_pack_multi_kernel(const BfPackDesc *__restrict__ tab) {
+    const BfPackDesc d = tab[blockIdx.y];
+    const int nf = d.wf ? d.kk * d.cin_pad * d.ldf : 0;
+    const int cout_pad = (d.Cout + 7) & ~7;
+    const int nb = d.wb ? d.kk * cout_pad * d.ldb : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+        if (i < nf) {
+            int e = i & 7, q = i >> 3;
+            int n = q % d.ldf;
+            q /= d.ldf;
+            int o = q % (d.cin_pad >> 3), t = q / (d.cin_pad >> 3);
+            int ci = 8 * o + e;
+            d.wf[i] = (bf16)((n < d.Cout && ci < d.Cin) ? d.w[((size_t)n * d.Cin + ci) * d.kk + t] : 0.f);
+        } else {
+            int j = i - nf;
+            int e = j & 7, q = j >> 3;
+            int n = q % d.ldb;
+            q /= d.ldb;
+            int o = q % (cout_pad >> 3), t = q / (cout_pad >> 3);
+            int co = 8 * o + e;
+            float v = (n < d.Cin && co < d.Cout) ? d.w[((size_t)co * d.Cin + n) * d.kk + t] : 0.f;
+            // destination row inside the (possibly stacked) K axis
+            size_t dst = ((size_t)(t * (d.kpad_b >> 3) + ((d.koff_b + co) >> 3)) * d.ldb + n) * 8 + ((d.koff_b + co) & 7);
+            d.wb[dst] = (bf16)v;
+        }
+    }
+}
+
+// ---- backward-weight ------------------------------------------------------------------------------------------------------
+struct BfWgrad {
+    const bf16 *x, *dy;
+    float *ws;              // [nsplit][KK][Cin][Cout] fp32 slabs
+    int ldx, lddy;
+    int B, Hi, Wi, Ho, Wo;
+    int Cin, Cout, k, s;
+    int n_ci_tiles;
+    int nseg_row, nseg_total, segs_per_split, P;
+    int xstride, dstride;   // bytes per pixel in the LDS images (bank-spread, see below)
+};
+
+// Waves: WI x WJ x WK = 4.  A workgroup owns a (32 WI input channels) x (32 WJ output channels) x all-taps slab; its WK
+// wave groups take alternate 16-pixel k-steps of every segment and are summed through LDS at the end.
+// LDS images: Xs[k rows][XW pixels][CIT channels], Ds[P pixels][COT channels], bf16, pixel stride chosen so that the four
+// pixel rows of one ds_read_b64_tr_b16 block start 16 banks apart (conflict-free for stride-1 layers).
+template <int KK, int WI, int WJ, int XL, int DL>
+__global__ __launch_bounds__(256) void bf16_wgrad_kernel(const BfWgrad g) {
+    constexpr int WK = 4 / (WI * WJ);
+    constexpr int CIT = 32 * WI, COT = 32 * WJ;
+    constexpr int K1 = KK == 9 ? 3 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = wave % WI, wj = (wave / WI) % WJ, wk = wave / (WI * WJ);
+    const int P = g.P, XW = (P - 1) * g.s + K1;
+    unsigned char *Xs = smem;
+    unsigned char *Ds = smem + K1 * XW * g.xstride;
+
+    const int ci0 = (blockIdx.y % g.n_ci_tiles) * CIT;
+    const int co0 = (blockIdx.y / g.n_ci_tiles) * COT;
+
+    f32x16 acc[KK];
+#pragma unroll
+    for (int u = 0; u < KK; ++u)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+
+    // transposing fragment reads: lane = 16 gi + 4 q + p supplies the address of pixel (8 h + 4 blk + q), channels
+    // 16 (gi & 1) + 4 p .. + 3 of its wave's 32-channel window; it receives channel 16 (gi & 1) + 4 q + p ... no:
+    // lane i of the group receives column i, i.e. channel 16 (gi & 1) + (lane & 15) = lane & 31 = the MFMA row / column.
+    const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3, lh = lane >> 5;
+    const int chan = 16 * (gi & 1) + 4 * pp;                 // first of the 4 channels this lane addresses
+    const int pix_in_step = 8 * lh + qq;                       // + 4 * blk
+    const int a_base = pix_in_step * g.s * g.xstride + (32 * wi + chan) * 2;
+    const int b_base = pix_in_step * g.dstride + (32 * wj + chan) * 2;
+
+    // staging slots: 16-byte pieces.  x: [kh][col][CIT/8], dy: [p][COT/8]
+    constexpr int CI8 = CIT / 8, CO8 = COT / 8;
+    const int nx = K1 * XW * CI8, nd = P * CO8;
+    int xkh[XL], xcol[XL], xo8[XL], dp[DL], do8[DL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        int i = t + 256 * j;
+        xo8[j] = i % CI8;
+        int q = i / CI8;
+        xcol[j] = q % XW;
+        xkh[j] = i < nx ? q / XW : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < DL; ++j) {
+        int i = t + 256 * j;
+        do8[j] = i % CO8;
+        dp[j] = i < nd ? i / CO8 : -1;
+    }
+
+    const int seg_begin = blockIdx.x * g.segs_per_split;
+    int seg_end = seg_begin + g.segs_per_split;
+    if (seg_end > g.nseg_total) seg_end = g.nseg_total;
+    const int pad = K1 / 2;
+
+    u32x4 rx[XL], rd[DL];
+    auto load_seg = [&](int seg) {
+        const int sr = seg % g.nseg_row, rowid = seg / g.nseg_row;
+        const int ho = rowid % g.Ho, b = rowid / g.Ho;
+        const int w0 = sr * P;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            rx[j] = u32x4{0u, 0u, 0u, 0u};
+            if (xkh[j] >= 0) {
+                const int iy = ho * g.s + xkh[j] - pad, ix = w0 * g.s + xcol[j] - pad, c = ci0 + 8 * xo8[j];
+                if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi && c < g.Cin)
+                    rx[j] = *(const u32x4 *)(g.x + ((size_t)(b * g.Hi + iy) * g.Wi + ix) * g.ldx + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) {
+            rd[j] = u32x4{0u, 0u, 0u, 0u};
+            if (dp[j] >= 0) {
+                const int ox = w0 + dp[j], c = co0 + 8 * do8[j];
+                if (ox < g.Wo && c < g.Cout)
+                    rd[j] = *(const u32x4 *)(g.dy + ((size_t)(b * g.Ho + ho) * g.Wo + ox) * g.lddy + c);
+            }
+        }
+    };
+    auto store_seg = [&]() {
+#pragma unroll
+        for (int j = 0; j < XL; ++j)
+            if (xkh[j] >= 0) *(u32x4 *)(Xs + (xkh[j] * XW + xcol[j]) * g.xstride + 16 * xo8[j]) = rx[j];
+#pragma unroll
+        for (int j = 0; j < DL; ++j)
+            if (dp[j] >= 0) *(u32x4 *)(Ds + dp[j] * g.dstride + 16 * do8[j]) = rd[j];
+    };
+    typedef __attribute__((address_space(3))) bf16x4 *lds_b4;
+    auto compute_seg = [&]() {
+        const int nsteps = P >> 4;
+        for (int st = wk; st < nsteps; st += WK) {
+            const int p0 = st * 16;
+            bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(Ds + b_base + p0 * g.dstride));
+            bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(Ds + b_base + (p0 + 4) * g.dstride));
+            bf16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int u = 0; u < KK; ++u) {
+                const int kh = u / K1, kw = u % K1;
+                const unsigned char *xa = Xs + a_base + ((kh * XW + kw) + p0 * g.s) * g.xstride;
+                bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(xa));
+                bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(xa + 4 * g.s * g.xstride));
+                bf16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[u], 0, 0, 0);
+            }
+        }
+    };
+
+    if (seg_begin < seg_end) {
+        load_seg(seg_begin);
+        for (int seg = seg_begin; seg < seg_end; ++seg) {
+            __syncthreads();                 // previous segment's reads are done
+            store_seg();
+            __syncthreads();
+            if (seg + 1 < seg_end) load_seg(seg + 1);
+            compute_seg();
+        }
+    }
+    __syncthreads();
+
+    // ---- slab write: sum the WK pixel groups through LDS, then [tap][ci][co] fp32 ----------------------------------
+    float *red = (float *)smem;              // [WI*WJ][KK][32][33]
+    const int lr = lane & 31;
+    for (int wsel = WK - 1; wsel >= 0; --wsel) {
+        if (wk == wsel) {
+            float *r = red + (size_t)((wj * WI + wi) * KK) * 32 * 33;
+#pragma unroll
+            for (int u = 0; u < KK; ++u)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float *e = r + (u * 32 + mfma_row(q, lh)) * 33 + lr;
+                    *e = (wsel == WK - 1) ? acc[u][q] : *e + acc[u][q];
+                }
+        }
+        __syncthreads();
+    }
+    float *slab = g.ws + (size_t)blockIdx.x * KK * g.Cin * g.Cout;
+    const int total = KK * CIT * COT;
+    for (int i = t; i < total; i += 256) {
+        const int co_l = i % COT;
+        int q = i / COT;
+        const int ci_l = q % CIT, u = q / CIT;
+        const int ci = ci0 + ci_l, co = co0 + co_l;
+        if (ci < g.Cin && co < g.Cout) {
+            const float *r = red + (size_t)(((co_l >> 5) * WI + (ci_l >> 5)) * KK + u) * 32 * 33;
+            slab[((size_t)u * g.Cin + ci) * g.Cout + co] = r[(ci_l & 31) * 33 + (co_l & 31)];
+        }
+    }
+}
+
+// fixed-order sum of the slabs -> OIHW fp32 (cin_real input channels)
+__global__ void bf16_wgrad_reduce_kernel(const float *__restrict__ ws, int nsplit, int KK, int Cin, int cin_real, int Cout,
+                                         float *__restrict__ dw) {
+    const int total = KK * Cin * Cout;
+    const size_t slab = (size_t)total;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout;
+        int q = i / Cout;
+        const int ci = q % Cin, u = q / Cin;
+        if (ci >= cin_real) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < nsplit; k += 4) {
+            s0 += ws[(size_t)k * slab + i];
+            s1 += ws[(size_t)(k + 1) * slab + i];
+            s2 += ws[(size_t)(k + 2) * slab + i];
+            s3 += ws[(size_t)(k + 3) * slab + i];
+        }
+        for (; k < nsplit; ++k) s0 += ws[(size_t)k * slab + i];
+        dw[((size_t)co * cin_real + ci) * KK + u] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+struct WgradPlan {
+    BfWgrad g;
+    int nsplit, ntiles, KK, WI, WJ;
+    size_t smem;
+};
+
+int plan_wgrad(WgradPlan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
+    BfWgrad &g = pl.g;
+    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Cout = Cout; g.k = k; g.s = s;
+    const int p = k / 2;
+    g.Ho = (Hi + 2 * p - k) / s + 1;
+    g.Wo = (Wi + 2 * p - k) / s + 1;
+    pl.KK = k * k;
+    pl.WI = Cin > 32 ? 2 : 1;
+    pl.WJ = Cout > 32 ? 2 : 1;
+    const int CIT = 32 * pl.WI, COT = 32 * pl.WJ;
+    g.n_ci_tiles = cdiv(Cin, CIT);
+    pl.ntiles = g.n_ci_tiles * cdiv(Cout, COT);
+    g.nseg_row = cdiv(g.Wo, 80);
+    g.P = (cdiv(g.Wo, g.nseg_row) + 15) & ~15;
+    g.nseg_row = cdiv(g.Wo, g.P);
+    g.nseg_total = B * g.Ho * g.nseg_row;
+    // pixel strides: 4 consecutive pixel rows of a transposed read must start 16 banks apart: stride = 16 or 48 dwords
+    g.xstride = CIT == 32 ? 64 : 192;
+    g.dstride = COT == 32 ? 64 : 192;
+    const int XW = (g.P - 1) * s + k;
+    const size_t stage = (size_t)k * XW * g.xstride + (size_t)g.P * g.dstride;
+    const size_t red = (size_t)pl.WI * pl.WJ * pl.KK * 32 * 33 * sizeof(float);
+    pl.smem = stage > red ? stage : red;
+    YH_REQUIRE(pl.smem <= 160 * 1024, "bf16_wgrad: LDS footprint %zu too large", pl.smem);
+    // split count: ~1024 workgroups per layer (HBM-bound: enough to fill the chip several times over)
+    static const int target = getenv("YH_BF16_WGRAD_BLOCKS") ? atoi(getenv("YH_BF16_WGRAD_BLOCKS")) : 1024;
+    int want = target / pl.ntiles;
+    if (want < 1) want = 1;
+    if (want > g.nseg_total) want = g.nseg_total;
+    g.segs_per_split = cdiv(g.nseg_total, want);
+    pl.nsplit = cdiv(g.nseg_total, g.segs_per_split);
+    return 0;
+}
+
+template <int KK, int WI, int WJ>
+int launch_wgrad_cfg(const WgradPlan &pl, hipStream_t st) {
+    const BfWgrad &g = pl.g;
+    const int K1 = KK == 9 ? 3 : 1;
+    const int XW = (g.P - 1) * g.s + K1;
+    const int xl = cdiv(K1 * XW * (4 * WI), 256), dl = cdiv(g.P * (4 * WJ), 256);
+#define YH_W(XL_, DL_)                                                                          \
+    do {                                                                                        \
+        auto kern = bf16_wgrad_kernel<KK, WI, WJ, XL_, DL_>;                                     \
+        if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;                 \
+        hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.ntiles), dim3(256), pl.smem, st, pl.g);      \
+        YH_CHECK_LAUNCH("bf16_wgrad");                                                          \
+        return 0;                                                                               \
+    } while (0)
+    if (xl <= 1 && dl <= 1) YH_W(1, 1);
+    if (xl <= 2 && dl <= 2) YH_W(2, 2);
+    if (xl <= 4 && dl <= 2) YH_W(4, 2);
+    if (xl <= 8 && dl <= 3) YH_W(8, 3);
+    if (xl <= 16 && dl <= 3) YH_W(16, 3);
+#undef YH_W
+    yh_set_error("bf16_wgrad: staging shape xl=%d dl=%d not instantiated", xl, dl);
+    return YH_E_UNSUPPORTED;
+}
+
+void fill_common(BfGemm &g, const void *in, int ldi, const void *w, int ldw, int Hi, int Wi, int Cin, int B) {
+    g.in = (const bf16 *)in; g.ldi = ldi; g.w = (const bf16 *)w; g.ldw = ldw;
+    g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.B = B;
+}
+
+}  // namespace
+
+extern "C" int yh_bf16_pack_multi(const void *table, int n, void *stream) {
+    YH_REQUIRE(table && n > 0, "bf16_pack_multi: bad argument");
+    hipLaunchKernelGGL(bf16_pack_multi_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const BfPackDesc *)table);
+    YH_CHECK_LAUNCH("bf16_pack_multi");
+    return 0;
+}
+
+extern "C" int yh_bf16_conv_blocks(int64_t M) { return (int)cdiv64(M, GEMM_BM); }
+
+extern "C" int yh_bf16_conv_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, int y_f32,
+                                float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream) {
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2) && !(k == 1 && s == 2), "bf16_conv_fwd: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "bf16_conv_fwd: bad argument");
+    YH_REQUIRE(ldx >= Cin && ldy >= Cout, "bf16_conv_fwd: ld smaller than channel count");
+    BfGemm g{};
+    const int p = k / 2;
+    fill_common(g, x, ldx, wf, ldwf, Hi, Wi, Cin, B);
+    g.bias = bias; g.out = y; g.stats = bn_partials; g.out_f32 = y_f32 ? 1 : 0;
+    g.Ho_f = (Hi + 2 * p - k) / s + 1; g.Wo_f = (Wi + 2 * p - k) / s + 1; g.ldo = ldy; g.N = Cout;
+    g.Yo = g.Ho_f; g.Xo = g.Wo_f; g.M = B * g.Yo * g.Xo;
+    g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
+    g.nTaps = k * k; g.Ktot = g.nTaps * Cin; g.accumulate = 0; g.dense = 1;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            int t = kh * k + kw;
+            g.tap_dy[t] = kh - p; g.tap_dx[t] = kw - p; g.tap_w[t] = t;
+        }
+    BfGemmSet gs{};
+    gs.c[0] = g;
+    return launch_set<1>(gs, (hipStream_t)stream);
+}
+
+extern "C" int yh_bf16_conv_bwd_data(const void *dy, int lddy, const void *dy2, int kcout1, const void *wb, int ldwb, void *dx,
+                                     int lddx, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int accumulate,
+                                     void *stream) {
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2) && !(k == 1 && s == 2), "bf16_conv_bwd_data: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(dy && wb && dx && B > 0 && Cin > 0 && Cout > 0 && Cout % 8 == 0, "bf16_conv_bwd_data: bad argument (Cout must be a multiple of 8: pad dY)");
+    YH_REQUIRE(lddy >= (dy2 ? kcout1 : Cout) && lddx >= Cin, "bf16_conv_bwd_data: ld smaller than channel count");
+    YH_REQUIRE(!dy2 || (k == 1 && kcout1 > 0 && kcout1 < Cout), "bf16_conv_bwd_data: the two-source form is pointwise only");
+    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
+    BfGemmSet gs{};
+    int ncls = 0;
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            BfGemm g{};
+            fill_common(g, dy, lddy, wb, ldwb, Ho, Wo, Cout, B);
+            g.in2 = (const bf16 *)dy2; g.ksplit = kcout1;
+            g.out = dx; g.out_f32 = 0;
+            g.Ho_f = Hi; g.Wo_f = Wi; g.ldo = lddx; g.N = Cin;
+            g.Yo = (Hi - ph + s - 1) / s; g.Xo = (Wi - pw + s - 1) / s; g.M = B * g.Yo * g.Xo;
+            g.osy = g.osx = s; g.ooy = ph; g.oox = pw; g.sy = g.sx = 1;
+            g.accumulate = accumulate; g.dense = (s == 1);
+            int nt = 0;
+            for (int kh = 0; kh < k; ++kh) {
+                if ((ph + p - kh) % s != 0) continue;
+                for (int kw = 0; kw < k; ++kw) {
+                    if ((pw + p - kw) % s != 0) continue;
+                    g.tap_dy[nt] = (ph + p - kh) / s; g.tap_dx[nt] = (pw + p - kw) / s; g.tap_w[nt] = kh * k + kw;
+                    ++nt;
+                }
+            }
+            YH_REQUIRE(nt > 0, "bf16_conv_bwd_data: residue class without taps");
+            g.nTaps = nt; g.Ktot = nt * Cout;
+            if (g.M == 0) continue;
+            gs.c[ncls++] = g;
+        }
+    hipStream_t st = (hipStream_t)stream;
+    switch (ncls) {
+        case 0: return 0;
+        case 1: return launch_set<1>(gs, st);
+        case 2: return launch_set<2>(gs, st);
+        case 3: return launch_set<3>(gs, st);
+        default: return launch_set<4>(gs, st);
+    }
+}
+
+extern "C" int64_t yh_bf16_conv_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
+    WgradPlan pl{};
+    if (plan_wgrad(pl, B, Hi, Wi, Cin, Cout, k, s)) return -1;
+    return (int64_t)pl.nsplit * k * k * Cin * Cout;
+}
+
+extern "C" int yh_bf16_conv_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                                       int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k, int s, void *stream) {
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2) && !(k == 1 && s == 2), "bf16_conv_bwd_weight: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(x && dy && dw && ws && B > 0 && Cin > 0 && Cout > 0 && cin_real > 0 && cin_real <= Cin, "bf16_conv_bwd_weight: bad argument");
+    YH_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && ldx >= Cin && lddy >= ((Cout + 7) & ~7) &&
+                   (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
+               "bf16_conv_bwd_weight: channels / ld must be multiples of 8 (dY readable up to roundup8(Cout)) and views 16-byte aligned");
+    WgradPlan pl{};
+    int rc = plan_wgrad(pl, B, Hi, Wi, Cin, Cout, k, s);
+    if (rc) return rc;
+    YH_REQUIRE(ws_floats >= (int64_t)pl.nsplit * k * k * Cin * Cout, "bf16_conv_bwd_weight: workspace too small");
+    pl.g.x = (const bf16 *)x; pl.g.dy = (const bf16 *)dy; pl.g.ws = ws; pl.g.ldx = ldx; pl.g.lddy = lddy;
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 3) {
+        if (pl.WI == 2 && pl.WJ == 2) rc = launch_wgrad_cfg<9, 2, 2>(pl, st);
+        else if (pl.WI == 2) rc = launch_wgrad_cfg<9, 2, 1>(pl, st);
+        else if (pl.WJ == 2) rc = launch_wgrad_cfg<9, 1, 2>(pl, st);
+        else rc = launch_wgrad_cfg<9, 1, 1>(pl, st);
+    } else {
+        if (pl.WI == 2 && pl.WJ == 2) rc = launch_wgrad_cfg<1, 2, 2>(pl, st);
+        else if (pl.WI == 2) rc = launch_wgrad_cfg<1, 2, 1>(pl, st);
+        else if (pl.WJ == 2) rc = launch_wgrad_cfg<1, 1, 2>(pl, st);
+        else rc = launch_wgrad_cfg<1, 1, 1>(pl, st);
+    }
+    if (rc) return rc;
+    const int total = k * k * Cin * Cout;
+    int blocks = cdiv(total, 256);
+    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, st, ws, pl.nsplit, k * k, Cin,
+                       cin_real, Cout, dw);
+    YH_CHECK_LAUNCH("bf16_wgrad_reduce");
+    return 0;
+}

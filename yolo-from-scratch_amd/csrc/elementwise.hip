@@ -9,35 +9,51 @@ namespace {
 
 constexpr int kMaxBlocks = 2048;
 
+// element access for the two activation types of the path: fp32 (16-byte float4) and bf16 (8-byte groups of four,
+// widened to fp32 in registers: every kernel below computes in fp32 whatever the storage type)
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
+__device__ __forceinline__ f32x4 ld4(const bf16 *p) { return __builtin_convertvector(*(const bf16x4 *)p, f32x4); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *(f32x4 *)p = v; }
+__device__ __forceinline__ void st4(bf16 *p, f32x4 v) { *(bf16x4 *)p = __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ float ld1(const float *p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16 *p) { return (float)*p; }
+__device__ __forceinline__ void st1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16 *p, float v) { *p = (bf16)v; }
+
 // ---------------------------------------------------------------------------------------------
-__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int ld,
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, T *__restrict__ dst, int C, int HW, int ld,
                                     int cpad, int64_t npix) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
         int64_t b = p / HW, hw = p - b * HW;
         const float *s = src + b * C * (int64_t)HW + hw;
-        float *d = dst + p * ld;
-        for (int c = 0; c < cpad; ++c) d[c] = c < C ? s[(int64_t)c * HW] : 0.f;
+        T *d = dst + p * ld;
+        for (int c = 0; c < cpad; ++c) st1(d + c, c < C ? s[(int64_t)c * HW] : 0.f);
     }
 }
 
 // uint8 HWC image batch -> NHWC fp32 in [0,1] (channel-padded): the reference's `from_numpy(...).float() / 255.0`
 // (train.py:115-117) evaluated on the device -- a true division, so the values are bit-identical -- 4x less PCIe traffic.
-__global__ void u8hwc_to_nhwc_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst, int C, int ld, int cpad,
+template <typename T>
+__global__ void u8hwc_to_nhwc_kernel(const uint8_t *__restrict__ src, T *__restrict__ dst, int C, int ld, int cpad,
                                      int64_t npix) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
         const uint8_t *s = src + p * C;
-        float *d = dst + p * ld;
-        for (int c = 0; c < cpad; ++c) d[c] = c < C ? (float)s[c] / 255.0f : 0.f;
+        T *d = dst + p * ld;
+        for (int c = 0; c < cpad; ++c) st1(d + c, c < C ? (float)s[c] / 255.0f : 0.f);
     }
 }
 
-__global__ void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int ld,
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T *__restrict__ src, float *__restrict__ dst, int C, int HW, int ld,
                                     int accumulate, int64_t total) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t hw = i % HW, q = i / HW;
         int c = (int)(q % C);
         int64_t b = q / C;
-        float v = src[(b * HW + hw) * ld + c];
+        float v = ld1(src + (b * HW + hw) * ld + c);
         dst[i] = accumulate ? dst[i] + v : v;
     }
 }
@@ -119,7 +135,8 @@ __global__ void pack_fold_multi_kernel(const FoldDesc *__restrict__ tab) {
 // ---------------------------------------------------------------------------------------------
 // column sums: stage 1 -> partial[blk][C], stage 2 -> out[C]
 // vector path (C % 4 == 0, 16-byte addressable rows): float4 columns x row groups, like the BN reductions
-__global__ void colsum_stage1_vec(const float *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
+template <typename T>
+__global__ void colsum_stage1_vec(const T *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
                                   int64_t rows_per_blk) {
     __shared__ float red[256 * 4];
     const int t = threadIdx.x, cq = C >> 2;
@@ -128,7 +145,7 @@ __global__ void colsum_stage1_vec(const float *__restrict__ x, int ldx, int64_t 
     if (r1 > M) r1 = M;
     f32x4 s = {0, 0, 0, 0};
     if (r_in < rg)
-        for (int64_t r = r0 + r_in; r < r1; r += rg) s += *(const f32x4 *)(x + r * ldx + 4 * c4);
+        for (int64_t r = r0 + r_in; r < r1; r += rg) s += ld4(x + r * ldx + 4 * c4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[t * 4 + e] = s[e];
     __syncthreads();
@@ -140,7 +157,8 @@ __global__ void colsum_stage1_vec(const float *__restrict__ x, int ldx, int64_t 
         *(f32x4 *)(part + (size_t)blockIdx.x * C + 4 * t) = a;
     }
 }
-__global__ void colsum_stage1(const float *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
+template <typename T>
+__global__ void colsum_stage1(const T *__restrict__ x, int ldx, int64_t M, int C, float *__restrict__ part,
                               int64_t rows_per_blk) {
     __shared__ float red[256];
     const int t = threadIdx.x;
@@ -153,7 +171,7 @@ __global__ void colsum_stage1(const float *__restrict__ x, int ldx, int64_t M, i
         int c = cb + c_in;
         float s = 0.f;
         if (c < C)
-            for (int64_t r = r0 + r_in; r < r1; r += rg) s += x[r * ldx + c];
+            for (int64_t r = r0 + r_in; r < r1; r += rg) s += ld1(x + r * ldx + c);
         red[t] = s;
         __syncthreads();
         if (r_in == 0 && c < C) {
@@ -229,8 +247,9 @@ __device__ __forceinline__ float silu_grad(float z) {
 }
 
 // a = silu(y*scale+shift) (+res); float4 over channels
-__global__ void bn_silu_fwd_kernel(const float *__restrict__ y, int ldy, const float *__restrict__ coef,
-                                   const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo,
+template <typename T>
+__global__ void bn_silu_fwd_kernel(const T *__restrict__ y, int ldy, const float *__restrict__ coef,
+                                   const T *__restrict__ res, int ldr, T *__restrict__ out, int ldo,
                                    int64_t M, int C, int H, int W, int upsample) {
     // (row, channel-quad) cursor advanced incrementally: the grid-stride index i = m * cq + c4 is never divided inside
     // the loop (a 64-bit division per float4 cost more VALU time than the four sigmoids)
@@ -243,42 +262,44 @@ __global__ void bn_silu_fwd_kernel(const float *__restrict__ y, int ldy, const f
     for (; m < M; m += dm, c4 += dc) {
         if (c4 >= cq) { c4 -= cq; if (++m >= M) break; }
         const int c = c4 << 2;
-        f32x4 v = *(const f32x4 *)(y + m * ldy + c);
+        f32x4 v = ld4(y + m * ldy + c);
         f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
         f32x4 a;
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[e] = silu_f(v[e] * sc[e] + sh[e]);
         if (res) {
-            f32x4 r = *(const f32x4 *)(res + m * ldr + c);
+            f32x4 r = ld4(res + m * ldr + c);
             a += r;
         }
         if (!upsample) {
-            *(f32x4 *)(out + m * ldo + c) = a;
+            st4(out + m * ldo + c, a);
         } else {
             const unsigned mu32 = (unsigned)m, q = mu32 / (unsigned)W, w = mu32 - q * (unsigned)W;      // M < 2^31
             const unsigned b = q / (unsigned)H, h = q - b * (unsigned)H;
-            float *o = out + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldo + c;
-            *(f32x4 *)(o) = a;
-            *(f32x4 *)(o + ldo) = a;
-            *(f32x4 *)(o + (size_t)2 * W * ldo) = a;
-            *(f32x4 *)(o + (size_t)2 * W * ldo + ldo) = a;
+            T *o = out + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldo + c;
+            st4(o, a);
+            st4(o + ldo, a);
+            st4(o + (size_t)2 * W * ldo, a);
+            st4(o + (size_t)2 * W * ldo + ldo, a);
         }
     }
 }
 
-__device__ __forceinline__ f32x4 load_da(const float *__restrict__ da, int ldda, int64_t m, int c, int H, int W,
+template <typename T>
+__device__ __forceinline__ f32x4 load_da(const T *__restrict__ da, int ldda, int64_t m, int c, int H, int W,
                                          int upsample) {
-    if (!upsample) return *(const f32x4 *)(da + m * ldda + c);
+    if (!upsample) return ld4(da + m * ldda + c);
     const unsigned mu32 = (unsigned)m, q = mu32 / (unsigned)W, w = mu32 - q * (unsigned)W;              // M < 2^31
     const unsigned b = q / (unsigned)H, h = q - b * (unsigned)H;
-    const float *p = da + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldda + c;
-    f32x4 a = *(const f32x4 *)p, b1 = *(const f32x4 *)(p + ldda);
-    f32x4 c1 = *(const f32x4 *)(p + (size_t)2 * W * ldda), d1 = *(const f32x4 *)(p + (size_t)2 * W * ldda + ldda);
+    const T *p = da + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldda + c;
+    f32x4 a = ld4(p), b1 = ld4(p + ldda);
+    f32x4 c1 = ld4(p + (size_t)2 * W * ldda), d1 = ld4(p + (size_t)2 * W * ldda + ldda);
     return (a + b1) + (c1 + d1);
 }
 
 // stage 1 of the backward: per-workgroup partial sums of dz and dz*xhat (per channel)
-__global__ void bn_silu_bwd_reduce_kernel(const float *__restrict__ da, int ldda, const float *__restrict__ y,
+template <typename T>
+__global__ void bn_silu_bwd_reduce_kernel(const T *__restrict__ da, int ldda, const T *__restrict__ y,
                                           int ldy, const float *__restrict__ coef, float *__restrict__ part,
                                           int64_t M, int C, int H, int W, int upsample, int64_t rows_per_blk) {
     extern __shared__ float red[];   // [256][8]
@@ -294,7 +315,7 @@ __global__ void bn_silu_bwd_reduce_kernel(const float *__restrict__ da, int ldda
         f32x4 mu = *(const f32x4 *)(coef + 2 * C + c), is = *(const f32x4 *)(coef + 3 * C + c);
         int64_t m = r0 + r_in;
         for (; m + rg < r1; m += 2 * rg) {          // two rows per trip: four 16-byte loads in flight per thread
-            f32x4 yv0 = *(const f32x4 *)(y + m * ldy + c), yv1 = *(const f32x4 *)(y + (m + rg) * ldy + c);
+            f32x4 yv0 = ld4(y + m * ldy + c), yv1 = ld4(y + (m + rg) * ldy + c);
             f32x4 g0 = load_da(da, ldda, m, c, H, W, upsample), g1 = load_da(da, ldda, m + rg, c, H, W, upsample);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -310,7 +331,7 @@ __global__ void bn_silu_bwd_reduce_kernel(const float *__restrict__ da, int ldda
             }
         }
         for (; m < r1; m += rg) {
-            f32x4 yv = *(const f32x4 *)(y + m * ldy + c);
+            f32x4 yv = ld4(y + m * ldy + c);
             f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -356,10 +377,11 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk,
     }
 }
 
-__global__ void bn_silu_bwd_apply_kernel(const float *__restrict__ da, int ldda, const float *__restrict__ y,
+template <typename T>
+__global__ void bn_silu_bwd_apply_kernel(const T *__restrict__ da, int ldda, const T *__restrict__ y,
                                          int ldy, const float *__restrict__ coef, const float *__restrict__ dgamma,
-                                         const float *__restrict__ dbeta, float *__restrict__ dy, int lddy,
-                                         float *__restrict__ dres, int lddres, int res_acc, int64_t M, int C, int H,
+                                         const float *__restrict__ dbeta, T *__restrict__ dy, int lddy,
+                                         T *__restrict__ dres, int lddres, int res_acc, int64_t M, int C, int H,
                                          int W, int upsample) {
     const int cq = C >> 2;
     const float inv_n = 1.0f / (float)M;
@@ -371,7 +393,7 @@ __global__ void bn_silu_bwd_apply_kernel(const float *__restrict__ da, int ldda,
     for (; m < M; m += dm, c4 += dc) {
         if (c4 >= cq) { c4 -= cq; if (++m >= M) break; }
         const int c = c4 << 2;
-        f32x4 yv = *(const f32x4 *)(y + m * ldy + c);
+        f32x4 yv = ld4(y + m * ldy + c);
         f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
         f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
         f32x4 mu = *(const f32x4 *)(coef + 2 * C + c), is = *(const f32x4 *)(coef + 3 * C + c);
@@ -383,17 +405,18 @@ __global__ void bn_silu_bwd_apply_kernel(const float *__restrict__ da, int ldda,
             float xh = (yv[e] - mu[e]) * is[e];
             o[e] = sc[e] * (dz - db[e] * inv_n - xh * dg[e] * inv_n);
         }
-        *(f32x4 *)(dy + m * lddy + c) = o;
+        st4(dy + m * lddy + c, o);
         if (dres) {
-            float *r = dres + m * lddres + c;
-            if (res_acc) g += *(const f32x4 *)r;
-            *(f32x4 *)r = g;
+            T *r = dres + m * lddres + c;
+            if (res_acc) g += ld4(r);
+            st4(r, g);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void maxpool5_fwd_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy,
+template <typename T>
+__global__ void maxpool5_fwd_kernel(const T *__restrict__ x, int ldx, T *__restrict__ y, int ldy,
                                     uint8_t *__restrict__ arg, int H, int W, int C, int64_t total) {
     const int cq = C >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -412,21 +435,22 @@ __global__ void maxpool5_fwd_kernel(const float *__restrict__ x, int ldx, float 
             for (int kw = 0; kw < 5; ++kw) {
                 int iw = w + kw - 2;
                 if (iw < 0 || iw >= W) continue;
-                f32x4 v = *(const f32x4 *)(x + ((b * H + ih) * W + iw) * ldx + c);
+                f32x4 v = ld4(x + ((b * H + ih) * W + iw) * ldx + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 5 + kw; }
                 first = false;
             }
         }
-        *(f32x4 *)(y + m * ldy + c) = best;
+        st4(y + m * ldy + c, best);
         uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
         *(uint32_t *)(arg + m * C + c) = packed;
     }
 }
 
-__global__ void maxpool5_bwd_kernel(const float *__restrict__ dy, int lddy, const uint8_t *__restrict__ arg,
-                                    float *__restrict__ dx, int lddx, int H, int W, int C, int64_t total) {
+template <typename T>
+__global__ void maxpool5_bwd_kernel(const T *__restrict__ dy, int lddy, const uint8_t *__restrict__ arg,
+                                    T *__restrict__ dx, int lddx, int H, int W, int C, int64_t total) {
     const int cq = C >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t m = i / cq;
@@ -444,15 +468,15 @@ __global__ void maxpool5_bwd_kernel(const float *__restrict__ dy, int lddy, cons
                 if (ow < 0 || ow >= W) continue;
                 int64_t om = (b * H + oh) * W + ow;
                 uint32_t packed = *(const uint32_t *)(arg + om * C + c);
-                f32x4 g = *(const f32x4 *)(dy + om * lddy + c);
+                f32x4 g = ld4(dy + om * lddy + c);
                 uint32_t want = (uint32_t)(kh * 5 + kw);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (((packed >> (8 * e)) & 0xffu) == want) acc[e] += g[e];
             }
         }
-        float *d = dx + m * lddx + c;
-        *(f32x4 *)d = *(const f32x4 *)d + acc;
+        T *d = dx + m * lddx + c;
+        st4(d, ld4(d) + acc);
     }
 }
 
@@ -467,32 +491,51 @@ inline int grid_for(int64_t work_items, int threads = 256) {
 
 }  // namespace
 
-extern "C" int yh_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, int ld, int cpad,
-                               void *stream) {
+template <typename T>
+static int nchw_to_nhwc_t(const float *src, T *dst, int B, int C, int H, int W, int ld, int cpad, void *stream) {
     YH_REQUIRE(src && dst && B > 0 && C > 0 && cpad >= C && ld >= cpad, "nchw_to_nhwc: bad argument");
     int64_t npix = (int64_t)B * H * W;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
                        H * W, ld, cpad, npix);
     YH_CHECK_LAUNCH("nchw_to_nhwc");
     return 0;
 }
+extern "C" int yh_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, int ld, int cpad, void *stream) {
+    return nchw_to_nhwc_t<float>(src, dst, B, C, H, W, ld, cpad, stream);
+}
+extern "C" int yh_bf16_nchw_to_nhwc(const float *src, void *dst, int B, int C, int H, int W, int ld, int cpad, void *stream) {
+    return nchw_to_nhwc_t<bf16>(src, (bf16 *)dst, B, C, H, W, ld, cpad, stream);
+}
 
-extern "C" int yh_u8hwc_to_nhwc(const uint8_t *src, float *dst, int B, int H, int W, int C, int ld, int cpad, void *stream) {
+template <typename T>
+static int u8hwc_to_nhwc_t(const uint8_t *src, T *dst, int B, int H, int W, int C, int ld, int cpad, void *stream) {
     YH_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && cpad >= C && ld >= cpad, "u8hwc_to_nhwc: bad argument");
     int64_t npix = (int64_t)B * H * W;
-    hipLaunchKernelGGL(u8hwc_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C, ld, cpad, npix);
+    hipLaunchKernelGGL(u8hwc_to_nhwc_kernel<T>, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, C, ld, cpad, npix);
     YH_CHECK_LAUNCH("u8hwc_to_nhwc");
     return 0;
 }
+extern "C" int yh_u8hwc_to_nhwc(const uint8_t *src, float *dst, int B, int H, int W, int C, int ld, int cpad, void *stream) {
+    return u8hwc_to_nhwc_t<float>(src, dst, B, H, W, C, ld, cpad, stream);
+}
+extern "C" int yh_bf16_u8hwc_to_nhwc(const uint8_t *src, void *dst, int B, int H, int W, int C, int ld, int cpad, void *stream) {
+    return u8hwc_to_nhwc_t<bf16>(src, (bf16 *)dst, B, H, W, C, ld, cpad, stream);
+}
 
-extern "C" int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, int ld, int accumulate,
-                               void *stream) {
+template <typename T>
+static int nhwc_to_nchw_t(const T *src, float *dst, int B, int C, int H, int W, int ld, int accumulate, void *stream) {
     YH_REQUIRE(src && dst && B > 0 && C > 0 && ld >= C, "nhwc_to_nchw: bad argument");
     int64_t total = (int64_t)B * C * H * W;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
                        H * W, ld, accumulate, total);
     YH_CHECK_LAUNCH("nhwc_to_nchw");
     return 0;
+}
+extern "C" int yh_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, int ld, int accumulate, void *stream) {
+    return nhwc_to_nchw_t<float>(src, dst, B, C, H, W, ld, accumulate, stream);
+}
+extern "C" int yh_bf16_nhwc_to_nchw(const void *src, float *dst, int B, int C, int H, int W, int ld, int accumulate, void *stream) {
+    return nhwc_to_nchw_t<bf16>((const bf16 *)src, dst, B, C, H, W, ld, accumulate, stream);
 }
 
 // merged stride-2 backward pack: W'[kh][c][co][pw*Cin + ci], see yh_conv_bwd_data_s2m
@@ -555,18 +598,25 @@ static int colsum_blocks(int64_t M) {
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 extern "C" int64_t yh_colsum_ws(int64_t M, int C) { return (int64_t)colsum_blocks(M) * C; }
-extern "C" int yh_colsum(const float *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream) {
+template <typename T>
+static int colsum_t(const T *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream) {
     YH_REQUIRE(x && out && ws && M > 0 && C > 0 && ldx >= C, "colsum: bad argument");
     int nblk = colsum_blocks(M);
     int64_t rows = cdiv64(M, nblk);
-    if (C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0)
-        hipLaunchKernelGGL(colsum_stage1_vec, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
+    if (C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ((uintptr_t)x & (4 * sizeof(T) - 1)) == 0)
+        hipLaunchKernelGGL(colsum_stage1_vec<T>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
     else
-        hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
+        hipLaunchKernelGGL(colsum_stage1<T>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, ws, rows);
     YH_CHECK_LAUNCH("colsum_stage1");
     hipLaunchKernelGGL(colsum_stage2, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, nblk, C, out);
     YH_CHECK_LAUNCH("colsum_stage2");
     return 0;
+}
+extern "C" int yh_colsum(const float *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream) {
+    return colsum_t<float>(x, ldx, M, C, out, ws, stream);
+}
+extern "C" int yh_bf16_colsum(const void *x, int ldx, int64_t M, int C, float *out, float *ws, void *stream) {
+    return colsum_t<bf16>((const bf16 *)x, ldx, M, C, out, ws, stream);
 }
 
 extern "C" int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
@@ -595,15 +645,24 @@ extern "C" int yh_bn_eval_coef(const float *gamma, const float *beta, const floa
         for (int ld__ : lds__) YH_REQUIRE(ld__ % 4 == 0, name ": ld=%d must be a multiple of 4", ld__); \
     } while (0)
 
-extern "C" int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
-                              int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
+template <typename T>
+static int bn_silu_fwd_t(const T *y, int ldy, const float *coef, const T *residual, int ldr, T *out, int ldo, int64_t M, int C,
+                         int H, int W, int upsample, void *stream) {
     YH_REQUIRE(y && coef && out && M > 0 && M < (1ll << 31), "bn_silu_fwd: bad argument");
     YH_REQ_VEC4("bn_silu_fwd", C, ldy, ldo, residual ? ldr : 0);
     YH_REQUIRE(!upsample || (H > 0 && W > 0 && M % ((int64_t)H * W) == 0), "bn_silu_fwd: upsample needs H, W");
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
+    hipLaunchKernelGGL(bn_silu_fwd_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
                        residual, ldr, out, ldo, M, C, H, W, upsample);
     YH_CHECK_LAUNCH("bn_silu_fwd");
     return 0;
+}
+extern "C" int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
+                              int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_fwd_t<float>(y, ldy, coef, residual, ldr, out, ldo, M, C, H, W, upsample, stream);
+}
+extern "C" int yh_bf16_bn_silu_fwd(const void *y, int ldy, const float *coef, const void *residual, int ldr, void *out,
+                                   int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_fwd_t<bf16>((const bf16 *)y, ldy, coef, (const bf16 *)residual, ldr, (bf16 *)out, ldo, M, C, H, W, upsample, stream);
 }
 
 extern "C" int yh_bn_bwd_blocks(int64_t M, int C) {
@@ -613,55 +672,95 @@ extern "C" int yh_bn_bwd_blocks(int64_t M, int C) {
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
-extern "C" int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef,
-                                     float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
+template <typename T>
+static int bn_silu_bwd_reduce_t(const T *da, int ldda, const T *y, int ldy, const float *coef, float *partials, int64_t M, int C,
+                                int H, int W, int upsample, void *stream) {
     YH_REQUIRE(da && y && coef && partials && M > 0 && M < (1ll << 31), "bn_silu_bwd_reduce: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_reduce", C, ldda, ldy);
     YH_REQUIRE(C <= 1024, "bn_silu_bwd_reduce: C too large");
     int nblk = yh_bn_bwd_blocks(M, C);
     int64_t rows = cdiv64(M, nblk);
-    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
                        da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
     YH_CHECK_LAUNCH("bn_silu_bwd_reduce");
     return 0;
 }
+extern "C" int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef,
+                                     float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_reduce_t<float>(da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, stream);
+}
+extern "C" int yh_bf16_bn_silu_bwd_reduce(const void *da, int ldda, const void *y, int ldy, const float *coef,
+                                          float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_reduce_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, partials, M, C, H, W, upsample, stream);
+}
 
-extern "C" int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, int ldy, const float *coef,
-                                    const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
-                                    float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C,
-                                    int H, int W, int upsample, void *stream) {
+template <typename T>
+static int bn_silu_bwd_apply_t(const T *da, int ldda, const T *y, int ldy, const float *coef,
+                               const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
+                               T *dy, int lddy, T *dres, int lddres, int res_accumulate, int64_t M, int C,
+                               int H, int W, int upsample, void *stream) {
     (void)gamma;
     YH_REQUIRE(da && y && coef && partials && dgamma && dbeta && dy && M > 0 && M < (1ll << 31) && nblk > 0, "bn_silu_bwd_apply: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_apply", C, ldda, ldy, lddy, dres ? lddres : 0);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
                        C);
     YH_CHECK_LAUNCH("bn_bwd_finalize");
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,
                        y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
     YH_CHECK_LAUNCH("bn_silu_bwd_apply");
     return 0;
 }
+extern "C" int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, int ldy, const float *coef,
+                                    const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
+                                    float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C,
+                                    int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_apply_t<float>(da, ldda, y, ldy, coef, partials, nblk, gamma, dgamma, dbeta, dy, lddy, dres, lddres,
+                                      res_accumulate, M, C, H, W, upsample, stream);
+}
+extern "C" int yh_bf16_bn_silu_bwd_apply(const void *da, int ldda, const void *y, int ldy, const float *coef,
+                                         const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
+                                         void *dy, int lddy, void *dres, int lddres, int res_accumulate, int64_t M, int C,
+                                         int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_apply_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, partials, nblk, gamma, dgamma, dbeta,
+                                     (bf16 *)dy, lddy, (bf16 *)dres, lddres, res_accumulate, M, C, H, W, upsample, stream);
+}
 
-extern "C" int yh_maxpool5_fwd(const float *x, int ldx, float *y, int ldy, uint8_t *argmax, int B, int H, int W, int C,
-                               void *stream) {
+template <typename T>
+static int maxpool5_fwd_t(const T *x, int ldx, T *y, int ldy, uint8_t *argmax, int B, int H, int W, int C, void *stream) {
     YH_REQUIRE(x && y && argmax && B > 0 && H > 0 && W > 0, "maxpool5_fwd: bad argument");
     YH_REQ_VEC4("maxpool5_fwd", C, ldx, ldy);
     int64_t total = (int64_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+    hipLaunchKernelGGL(maxpool5_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
                        argmax, H, W, C, total);
     YH_CHECK_LAUNCH("maxpool5_fwd");
     return 0;
 }
+extern "C" int yh_maxpool5_fwd(const float *x, int ldx, float *y, int ldy, uint8_t *argmax, int B, int H, int W, int C,
+                               void *stream) {
+    return maxpool5_fwd_t<float>(x, ldx, y, ldy, argmax, B, H, W, C, stream);
+}
+extern "C" int yh_bf16_maxpool5_fwd(const void *x, int ldx, void *y, int ldy, uint8_t *argmax, int B, int H, int W, int C,
+                                    void *stream) {
+    return maxpool5_fwd_t<bf16>((const bf16 *)x, ldx, (bf16 *)y, ldy, argmax, B, H, W, C, stream);
+}
 
-extern "C" int yh_maxpool5_bwd(const float *dy, int lddy, const uint8_t *argmax, float *dx, int lddx, int B, int H,
-                               int W, int C, void *stream) {
+template <typename T>
+static int maxpool5_bwd_t(const T *dy, int lddy, const uint8_t *argmax, T *dx, int lddx, int B, int H, int W, int C, void *stream) {
     YH_REQUIRE(dy && dx && argmax && B > 0 && H > 0 && W > 0, "maxpool5_bwd: bad argument");
     YH_REQ_VEC4("maxpool5_bwd", C, lddy, lddx);
     int64_t total = (int64_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, argmax,
+    hipLaunchKernelGGL(maxpool5_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, lddy, argmax,
                        dx, lddx, H, W, C, total);
     YH_CHECK_LAUNCH("maxpool5_bwd");
     return 0;
+}
+extern "C" int yh_maxpool5_bwd(const float *dy, int lddy, const uint8_t *argmax, float *dx, int lddx, int B, int H,
+                               int W, int C, void *stream) {
+    return maxpool5_bwd_t<float>(dy, lddy, argmax, dx, lddx, B, H, W, C, stream);
+}
+extern "C" int yh_bf16_maxpool5_bwd(const void *dy, int lddy, const uint8_t *argmax, void *dx, int lddx, int B, int H,
+                                    int W, int C, void *stream) {
+    return maxpool5_bwd_t<bf16>((const bf16 *)dy, lddy, argmax, (bf16 *)dx, lddx, B, H, W, C, stream);
 }
 
 extern "C" int yh_add_int64(int64_t *p, int64_t v, void *stream) {

@@ -114,7 +114,8 @@ __device__ __forceinline__ float bce_logits(float x, float z) {
 
 struct LossArgs {
     const float *pred[3], *tgt[3];
-    float *dpred[3];
+    void *dpred[3];         // float, or bf16 when dbf16 (the bf16 path's head gradient)
+    int dbf16, ldd[3];      // ldd: elements per PIXEL of dpred (3 anchors x ch, possibly padded); 0 = contiguous
     float anchors[18];
     int grid[3];
     int64_t cells[3];       // B*G*G*3 per scale
@@ -147,10 +148,15 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
     if (cell < a.cells[s]) {
         const float *p = a.pred[s] + cell * ch;
         const float *t = a.tgt[s] + cell * ch;
-        float *d = a.dpred[s] ? a.dpred[s] + cell * ch : nullptr;
+        const bool hasd = a.dpred[s] != nullptr;
+        const int64_t dbase = a.ldd[s] ? (cell / 3) * a.ldd[s] + (cell % 3) * ch : cell * ch;
+        auto dstore = [&](int e, float v) {
+            if (a.dbf16) ((__bf16 *)a.dpred[s])[dbase + e] = (__bf16)v;
+            else ((float *)a.dpred[s])[dbase + e] = v;
+        };
         const float x = p[4], z = t[4];
         lobj = (double)bce_logits(x, z);
-        if (d) d[4] = (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]);
+        if (hasd) dstore(4, (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]));
         if (z > 0.5f) {
             int an = (int)(cell % 3);
             int64_t q = cell / 3;
@@ -167,18 +173,18 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
             box[2] = aw * (two_w * two_w);
             box[3] = ah * (two_h * two_h);
             lbox = (double)ciou_term(box, tb, 1e-7f, gb);
-            if (d) {
+            if (hasd) {
                 float kb = gbox / (float)npos;
-                d[0] = gb[0] * (2.0f * sg[0] * (1.f - sg[0]) / (float)G) * kb;
-                d[1] = gb[1] * (2.0f * sg[1] * (1.f - sg[1]) / (float)G) * kb;
-                d[2] = gb[2] * (aw * 8.0f * sg[2] * sg[2] * (1.f - sg[2])) * kb;
-                d[3] = gb[3] * (ah * 8.0f * sg[3] * sg[3] * (1.f - sg[3])) * kb;
+                dstore(0, gb[0] * (2.0f * sg[0] * (1.f - sg[0]) / (float)G) * kb);
+                dstore(1, gb[1] * (2.0f * sg[1] * (1.f - sg[1]) / (float)G) * kb);
+                dstore(2, gb[2] * (aw * 8.0f * sg[2] * sg[2] * (1.f - sg[2])) * kb);
+                dstore(3, gb[3] * (ah * 8.0f * sg[3] * sg[3] * (1.f - sg[3])) * kb);
             }
             float kc = a.nc > 0 ? gcls / ((float)npos * (float)a.nc) : 0.f;
             for (int c = 0; c < a.nc; ++c) {
                 float xc = p[5 + c], zc = t[5 + c];
                 lcls += (double)bce_logits(xc, zc);
-                if (d) d[5 + c] = (yh_sigmoid(xc) - zc) * kc;
+                if (hasd) dstore(5 + c, (yh_sigmoid(xc) - zc) * kc);
             }
         }
     }
@@ -337,7 +343,7 @@ __global__ void eval_counts_kernel(const EvalArgs a) {
     m = __ballot(fn); if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counts[2], (unsigned long long)__popcll(m));
 }
 
-int fill_args(LossArgs &a, const float *const pred[3], const float *const target[3], float *const dpred[3],
+int fill_args(LossArgs &a, const float *const pred[3], const float *const target[3], void *const dpred[3],
               const float *anchors, const int grid[3], int B, int nc, float img, const float *loss_w,
               const float *grad_w, float *out, float *ws) {
     YH_REQUIRE(pred && target && anchors && grid && out && ws && B > 0 && nc >= 0 && img > 0.f, "yolo_loss: bad argument");
@@ -373,15 +379,28 @@ extern "C" int64_t yh_loss_ws(const int grid[3], int B) {
 extern "C" int yh_yolo_loss(const float *const pred[3], const float *const target[3], float *const dpred[3],
                             const float *anchors, const int grid[3], int B, int nc, float loss_img_size,
                             const float *loss_w, const float *grad_w, float *out, float *ws, void *stream) {
+    return yh_yolo_loss_ex(pred, target, (void *const *)dpred, 0, nullptr, anchors, grid, B, nc, loss_img_size, loss_w, grad_w, out, ws,
+                           stream);
+}
+
+extern "C" int yh_yolo_loss_ex(const float *const pred[3], const float *const target[3], void *const dpred[3], int dpred_bf16,
+                               const int dpred_ld[3], const float *anchors, const int grid[3], int B, int nc, float loss_img_size,
+                               const float *loss_w, const float *grad_w, float *out, float *ws, void *stream) {
     LossArgs a{};
     int rc = fill_args(a, pred, target, dpred, anchors, grid, B, nc, loss_img_size, loss_w, grad_w, out, ws);
     if (rc) return rc;
+    a.dbf16 = dpred_bf16 ? 1 : 0;
+    for (int s = 0; s < 3; ++s) {
+        a.ldd[s] = dpred_ld ? dpred_ld[s] : 0;
+        YH_REQUIRE(a.ldd[s] == 0 || a.ldd[s] >= 3 * (5 + nc), "yolo_loss: dpred_ld[%d]=%d smaller than 3*(5+nc)", s, a.ldd[s]);
+    }
     YH_REQUIRE(((uintptr_t)ws & 7) == 0, "yolo_loss: workspace must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     YH_HIP(hipMemsetAsync(a.counts, 0, 4 * sizeof(int), st));
     const int ch = 5 + nc;
     for (int s = 0; s < 3; ++s)
-        if (a.dpred[s]) YH_HIP(hipMemsetAsync(a.dpred[s], 0, (size_t)a.cells[s] * ch * sizeof(float), st));
+        if (a.dpred[s])      // also zeroes the padding channels of a padded bf16 gradient (they meet zero weight rows)
+            YH_HIP(hipMemsetAsync(a.dpred[s], 0, (size_t)(a.cells[s] / 3) * (a.ldd[s] ? a.ldd[s] : 3 * ch) * (a.dbf16 ? 2 : sizeof(float)), st));
     const int nb = a.blk_begin[3];
     YH_REQUIRE(nb > 0, "yolo_loss: no cells");
     hipLaunchKernelGGL(loss_count_kernel, dim3(nb), dim3(256), 0, st, a);
