@@ -26,7 +26,10 @@ NC, IMG, BATCH = 1, 640, 64          # BASELINE.json configs[1]
 #   YH_BENCH_SHAPE=80,640,64  or  80,1280,16
 if os.environ.get("YH_BENCH_SHAPE"):
     NC, IMG, BATCH = (int(v) for v in os.environ["YH_BENCH_SHAPE"].split(","))
+# YH_BENCH_DTYPE=bf16: the bf16 path of configs 3-4 (informational too: the headline line is fp32, the reference's arithmetic)
+DTYPE = os.environ.get("YH_BENCH_DTYPE", "f32")
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md, HBM3E spec (6290 measured with a float4 copy)
 
 
 def plan_conv_flops(plan):
@@ -38,6 +41,18 @@ def plan_conv_flops(plan):
             fl += f
             fw += f if r.wino_f else 0
     return fl, fw   # per image: all forward convs, and the part on the Winograd kernel
+
+
+def plan_conv_bytes(plan):
+    """Algorithmic activation bytes of the forward convolutions per image: every conv reads its input view once
+    and writes its output once, in the plan's storage type (head outputs fp32)."""
+    from yolo_from_scratch_amd.graph import ConvRec
+    nb = 0
+    for r in plan.recs:
+        if isinstance(r, ConvRec):
+            esz = 2 if plan.bf16 else 4
+            nb += r.x.H * r.x.W * r.weight.shape[1] * esz + r.Ho * r.Wo * r.cout * (esz if r.bn is not None else 4)
+    return nb
 
 
 def time_forward_convs(trainer, plan, imgs, targets, steps):
@@ -64,7 +79,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD):
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD, L.OP_BF16_CONV_FWD):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
@@ -179,7 +194,7 @@ def main():
 
     torch.manual_seed(0)                                   # identical replicas
     model = y.YOLO(num_classes=NC, img_size=IMG).to(dev)
-    trainer = y.HipTrainer(model, lr=1e-3, max_norm=10.0)
+    trainer = y.HipTrainer(model, lr=1e-3, max_norm=10.0, dtype=DTYPE)
     imgs = torch.rand(BATCH, 3, IMG, IMG, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
     targets = [t.to(dev) for t in y.synthetic_targets(BATCH, NC, IMG, 8, 2000 + rank)]
 
@@ -203,16 +218,38 @@ def main():
     loss = trainer.loss_out[:4].tolist()
 
     result = {
-        "metric": "images/sec training step, 640x640 bs=64/GPU" if (NC, IMG, BATCH) == (1, 640, 64) else
-                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} (informational shape)", "value": round(BATCH * world * args.steps / elapsed, 2),
+        "metric": "images/sec training step, 640x640 bs=64/GPU" if (NC, IMG, BATCH, DTYPE) == (1, 640, 64, "f32") else
+                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} {DTYPE} (informational shape)", "value": round(BATCH * world * args.steps / elapsed, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"nc={NC} {IMG}x{IMG} bs={BATCH}/GPU full training step (fwd+loss+bwd+clip10+Adam), model size s, fp32 MFMA",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": f"nc={NC} {IMG}x{IMG} bs={BATCH}/GPU full training step (fwd+loss+bwd+clip10+Adam), model size s, "
+                               + ("fp32 MFMA" if DTYPE == "f32" else "bf16 MFMA convolutions, bf16 activations, fp32 master weights / statistics / loss"),
                    "global_batch": BATCH * world, "parallelism": f"dp{world}"},
         "loss": [round(v, 6) for v in loss],
     }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and DTYPE == "bf16":
+        # bf16: every layer of this network is HBM-bound, so the roofline is bytes: algorithmic activation bytes of
+        # the forward convolutions (each input view read once, each output written once) / HIP-event time of those launches
+        plan = model._plan_for(imgs)
+        from yolo_from_scratch_amd import _lib as L
+        conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
+        nbytes = plan_conv_bytes(plan) * BATCH
+        flops = plan_conv_flops(plan)[0] * BATCH
+        ach = nbytes / (conv_ms * 1e-3) / 1e9
+        bn_ms = per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BF16_BN_SILU_FWD, 0.0)
+        result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                              "kernel": "forward convolutions: bf16_gemm_kernel (gather implicit GEMM on v_mfma_f32_32x32x16_bf16)",
+                              "kernel_ms_per_step": round(conv_ms, 3), "launches_per_step": n_launch,
+                              "algorithmic_gbytes_per_step": round(nbytes / 1e9, 3),
+                              "algorithmic_gflop_per_step": round(flops / 1e9, 2),
+                              "conv_tflops": round(flops / (conv_ms * 1e-3) / 1e12, 1),
+                              "conv_bn_silu_forward_ms_per_step": round(conv_ms + bn_ms, 3),
+                              "whole_forward_ms_serial": round(per_kind["whole_forward_serial"], 3),
+                              "whole_forward_ms_with_lanes": round(per_kind["whole_forward_lanes"], 3)}
+        result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items(), key=lambda kv: str(kv[0]))}
+    if rank == 0 and not args.no_roofline and DTYPE == "f32":
         plan = model._plan_for(imgs)
         from yolo_from_scratch_amd import _lib as L
         conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)

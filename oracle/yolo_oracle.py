@@ -41,35 +41,65 @@ W_BOX, W_CLS = 0.05, 0.5              # train.py:879
 # --------------------------------------------------------------------------------------------
 # model graph
 # --------------------------------------------------------------------------------------------
+class _RoundBf16(torch.autograd.Function):
+    """Storage emulation of the bf16 path (no counterpart in the reference, which is fp32 only): the value is rounded
+    to bf16 on the way forward, its gradient on the way back; all arithmetic stays fp32."""
+
+    @staticmethod
+    def forward(ctx, t, fwd, bwd):
+        ctx.bwd = bwd
+        return t.to(torch.bfloat16).to(torch.float32) if fwd else t.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(torch.float32) if ctx.bwd else g), None, None
+
+
 class _Net:
     """Evaluates blocks against a parameter dict.  `training` selects batch statistics
-    (and in-place running-stat updates, as nn.BatchNorm2d does) or running statistics."""
+    (and in-place running-stat updates, as nn.BatchNorm2d does) or running statistics.
 
-    def __init__(self, P: Dict[str, torch.Tensor], training: bool):
-        self.P, self.training = P, training
+    storage="bf16" models WHERE the product's bf16 path (BASELINE configs 3-4) rounds: the image, the per-step weight
+    packs, every stored conv output / activation and every stored activation gradient are rounded to bf16, while
+    convolution sums, BatchNorm statistics, SiLU, the loss and the parameter gradients stay fp32.  It is an error MODEL
+    used to derive the bf16 tests' tolerances (how far a correct bf16-storage pipeline drifts from fp32); the fp32 mode
+    is the pinned restatement of the reference."""
 
-    def _bn_silu(self, y, bn):
+    def __init__(self, P: Dict[str, torch.Tensor], training: bool, storage: str = "f32"):
+        self.P, self.training, self.bf16 = P, training, storage == "bf16"
+
+    def q(self, t, fwd=True, bwd=True):
+        return _RoundBf16.apply(t, fwd, bwd) if self.bf16 else t
+
+    def _w(self, key):                       # the bf16 weight pack: rounded copy, fp32 master gradient
+        return self.q(self.P[key], True, False)
+
+    def _bn_silu(self, y, bn, residual=None):
         P = self.P
+        y = self.q(y)                        # stored pre-BN output (statistics are those of the stored values); dY stored
         out = F.batch_norm(y, P[f"{bn}.running_mean"], P[f"{bn}.running_var"],
                            P[f"{bn}.weight"], P[f"{bn}.bias"], self.training, BN_MOMENTUM, BN_EPS)
         if self.training and f"{bn}.num_batches_tracked" in P:
             P[f"{bn}.num_batches_tracked"] += 1
-        return F.silu(out)
+        a = F.silu(out)
+        if residual is not None:
+            a = residual + a
+        return self.q(a)                     # stored activation; its gradient (sum over consumers) stored
 
-    def cbs(self, x, name, stride=1):
+    def cbs(self, x, name, stride=1, residual=None):
         """ConvBlock = bias-free conv -> BN -> SiLU (train.py:253-265); padding = k//2."""
-        w = self.P[f"{name}.conv.weight"]
-        return self._bn_silu(F.conv2d(x, w, None, stride, w.shape[-1] // 2), f"{name}.bn")
+        w = self._w(f"{name}.conv.weight")
+        return self._bn_silu(F.conv2d(x, w, None, stride, w.shape[-1] // 2), f"{name}.bn", residual)
 
     def inline(self, x, conv, bn, stride):
         """Conv2d(bias=True) -> BN -> SiLU written inline in the reference (train.py:401-404,
         408, 413, 418 and SPPF 236-241)."""
-        w = self.P[f"{conv}.weight"]
+        w = self._w(f"{conv}.weight")
         return self._bn_silu(F.conv2d(x, w, self.P[f"{conv}.bias"], stride, w.shape[-1] // 2), bn)
 
     def bottleneck(self, x, name):
         """x + CB3x3(CB3x3(x)) (train.py:295-306); shortcut always active in this net."""
-        return x + self.cbs(self.cbs(x, f"{name}.conv1"), f"{name}.conv2")
+        return self.cbs(self.cbs(x, f"{name}.conv1"), f"{name}.conv2", residual=x)
 
     def c3(self, x, name):
         """conv3(cat[bottlenecks(conv1 x), conv2 x]) (train.py:288-293)."""
@@ -91,13 +121,15 @@ class _Net:
     def head(self, x, name):
         """CB3x3, CB3x3, Conv1x1(+bias) (train.py:452-466)."""
         x = self.cbs(self.cbs(x, f"{name}.0"), f"{name}.1")
-        return F.conv2d(x, self.P[f"{name}.2.weight"], self.P[f"{name}.2.bias"])
+        o = F.conv2d(x, self._w(f"{name}.2.weight"), self.P[f"{name}.2.bias"])
+        return self.q(o, False, True)        # fp32 head output, bf16 head gradient
 
 
 def forward(P: Dict[str, torch.Tensor], x: torch.Tensor, num_classes: int,
-            training: bool = True) -> List[torch.Tensor]:
+            training: bool = True, storage: str = "f32") -> List[torch.Tensor]:
     """YOLO.forward (train.py:568-632): NCHW image batch -> three (B,G,G,3,5+nc) tensors."""
-    n = _Net(P, training)
+    n = _Net(P, training, storage)
+    x = n.q(x, True, False)
     up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
     # backbone (train.py:572-576)
     s = n.inline(n.inline(x, "stem.0", "stem.1", 2), "stem.3", "stem.4", 2)

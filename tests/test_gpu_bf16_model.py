@@ -1,0 +1,190 @@
+"""bf16 training path (BASELINE configs 3-4: nc=80, "bf16 MFMA implicit-GEMM conv") at model level.
+
+Tolerances and where they come from.  The bf16 path rounds every STORED activation, pre-BN conv output, activation
+gradient and per-step weight pack to 8 mantissa bits (relative error <= 2^-9 = 0.2 %) while convolution sums,
+BatchNorm statistics, SiLU, the loss and every parameter gradient stay fp32 on fp32 master weights.  How far a
+*correct* pipeline of that kind drifts from the reference's fp32 arithmetic is not a guess here: the CPU oracle has a
+storage-emulation mode (`orc.forward(..., storage="bf16")`: fp32 math, straight-through bf16 rounding at the same
+places) and the tests measure its drift next to the HIP path's:
+  * losses: the emulation sits within 1e-3..4e-3 of fp32 (box term the largest); both it and the HIP path are held to
+    1e-2 relative of the fp32 oracle;
+  * weight gradients are the residue of heavily cancelling sums (BatchNorm zero-means every layer's input, the
+    objectness gradient is almost constant over 10^5..10^6 cells), so 0.2 % storage noise becomes cosines of ~0.995
+    (heads), ~0.985 (neck) and ~0.95 (backbone, behind the max-pools whose argmax ties multiply in bf16) against fp32 --
+    in the emulation.  The HIP path must reach the emulation's cosine minus 0.03 on every tensor, and 0.90 absolutely
+    (slack 0.06 and no absolute floor for the 64..256-entry BatchNorm vectors: a noisier statistic, and a few of them are
+    noise-dominated at initialisation in the emulation as well);
+  * the global gradient norm within 5 %.
+The seven conv biases in front of BatchNorm (quirk Q2: true gradient 0) are excluded as in the fp32 tests."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-2
+COS_SLACK = 0.03        # HIP cosine vs fp32 may be this much below the storage emulation's cosine vs fp32
+COS_FLOOR = 0.90
+COS_MIN = 0.90          # full-size / cross-path checks without an emulation next to them
+NORM_RTOL = 0.10
+
+
+def api():
+    import yolo_from_scratch_amd as y
+    return y
+
+
+Q2 = {"stem.0.bias", "stem.3.bias", "backbone_p3.1.bias", "backbone_p4.0.bias", "backbone_p5.0.bias",
+      "sppf.conv1.bias", "sppf.conv2.bias"}     # conv biases cancelled by the following BN: gradients are rounding noise
+
+
+def _cos(a, b):
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("nc,S,B", [(80, 320, 2), (1, 320, 2), (3, 640, 1)])
+def test_bf16_step_tracks_fp32_oracle(nc, S, B):
+    y = api()
+    from oracle import yolo_oracle as orc
+    torch.manual_seed(0)
+    ref = y.YOLO(num_classes=nc, img_size=S)
+    names = [n for n, _ in ref.named_parameters()]
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(71))
+    tg = y.synthetic_targets(B, nc, S, 8, 72)
+    G, losses = {}, {}
+    for storage in ("f32", "bf16"):          # the pinned fp32 oracle, and its bf16-storage error model
+        P = {k: v.clone() for k, v in ref.state_dict().items()}
+        for n in names:
+            P[n].requires_grad_(True)
+        out = orc.loss_multiscale(orc.forward(P, x, nc, True, storage), tg, orc.anchors_of(P), nc)
+        out[0].backward()
+        losses[storage] = np.array([float(v) for v in out])
+        G[storage] = {n: P[n].grad.reshape(-1).double() for n in names}
+    m = ref.cuda()
+    tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0, dtype="bf16")
+    out = tr.step(x.cuda(), [t.cuda() for t in tg])[:4].cpu().numpy().copy()
+    assert m._plan_for(x.cuda()).dtype == "bf16"
+    np.testing.assert_allclose(losses["bf16"], losses["f32"], rtol=LOSS_RTOL, atol=1e-6)      # the model's own drift
+    np.testing.assert_allclose(out, losses["f32"], rtol=LOSS_RTOL, atol=1e-5)
+    total = float(torch.sqrt(sum((g ** 2).sum() for g in G["f32"].values())))
+    assert abs(float(tr.norm) - total) <= 0.05 * total
+    coef = min(1.0, 10.0 / (float(tr.norm) + 1e-6))    # the trainer scaled its flat gradient by the clip coefficient in place
+    params = dict(m.named_parameters())
+    checked, worst = 0, 1.0
+    for n in names:
+        g_ref = G["f32"][n]
+        nr = float(g_ref.norm())
+        if n in Q2 or nr < 1e-3 * total or g_ref.numel() < 64:
+            continue                          # no signal (Q2 / tiny norm) or too small for a meaningful cosine
+        g_got = params[n].grad.detach().cpu().reshape(-1).double() / coef
+        c_hip, c_emu = _cos(g_ref, g_got), _cos(g_ref, G["bf16"][n])
+        small = g_ref.numel() < 1024          # BatchNorm vectors (64..256 entries): a noisier statistic, twice the slack
+        # (a few BatchNorm vectors have a noise-dominated gradient at initialisation under ANY bf16 storage -- the emulation
+        # itself drops to ~0.2 there -- so the absolute floor is applied to the large weight tensors only)
+        assert c_hip >= c_emu - COS_SLACK * (2 if small else 1), (n, c_hip, c_emu)
+        assert small or c_hip >= COS_FLOOR, (n, c_hip, c_emu)
+        assert abs(float(g_got.norm()) - nr) <= NORM_RTOL * nr, (n, float(g_got.norm()), nr)
+        worst = min(worst, c_hip)
+        checked += 1
+    assert checked >= 40
+
+
+def test_bf16_autograd_path_and_module_interface():
+    """set_compute_dtype('bf16') keeps the module interface: fp32 NCHW in, fp32 head tensors out, .backward() through
+    the reference-style loss, gradients in param.grad (fp32); eval-mode forwards keep running fp32."""
+    y = api()
+    nc, S, B = 3, 160, 2
+    torch.manual_seed(0)
+    m = y.YOLO(num_classes=nc, img_size=S).cuda().set_compute_dtype("bf16")
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(5)).cuda()
+    tg = [t.cuda() for t in y.synthetic_targets(B, nc, S, 6, 6)]
+    preds = m(x)
+    assert all(p.dtype == torch.float32 and p.shape == (B, S // s, S // s, 3, 5 + nc) for p, s in zip(preds, (8, 16, 32)))
+    loss = y.yolo_loss_multiscale(preds, tg, m.anchors, nc)[0]
+    loss.backward()
+    g_bf16 = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    assert all(g.dtype == torch.float32 and torch.isfinite(g).all() for g in g_bf16.values())
+    # same model, fp32 compute: the two paths agree to bf16 accuracy
+    m.zero_grad()
+    m.set_compute_dtype("f32")
+    loss32 = y.yolo_loss_multiscale(m(x), tg, m.anchors, nc)[0]
+    loss32.backward()
+    assert abs(float(loss) - float(loss32)) <= LOSS_RTOL * abs(float(loss32))
+    big = [n for n, p in m.named_parameters() if p.numel() >= 4096 and n.endswith("conv.weight")]
+    for n in big:
+        a, b = g_bf16[n].reshape(-1).double(), dict(m.named_parameters())[n].grad.reshape(-1).double()
+        if float(b.norm()) > 1e-4:
+            assert float(a @ b / (a.norm() * b.norm())) >= COS_MIN, n
+    # fused trainer == autograd path on the bf16 plan (same op lists): bitwise-equal loss
+    m.set_compute_dtype("bf16")
+    torch.manual_seed(0)
+    m2 = y.YOLO(num_classes=nc, img_size=S).cuda()
+    tr = y.HipTrainer(m2, lr=1e-3, max_norm=None, dtype="bf16")
+    out = tr.step(x, tg)
+    assert abs(float(out[0]) - float(loss)) <= 1e-6 * abs(float(loss))
+    m.eval()
+    with torch.no_grad():
+        pe = m(x)
+    assert m._plan_for(x).dtype == "f32" and all(torch.isfinite(p).all() for p in pe)
+
+
+def test_bf16_training_learns_and_is_reproducible():
+    y = api()
+    nc, S, B = 2, 256, 4
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(5)).cuda()
+    tg = [t.cuda() for t in y.synthetic_targets(B, nc, S, 6, 6)]
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        m = y.YOLO(num_classes=nc, img_size=S).cuda()
+        tr = y.HipTrainer(m, lr=2e-3, max_norm=10.0, dtype="bf16")
+        hist = torch.stack([tr.step(x, tg)[:4].clone() for _ in range(120)]).cpu()
+        runs.append((hist, tr.flat_p.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])      # bitwise reproducible
+    hist = runs[0][0]
+    assert torch.isfinite(hist).all()
+    assert float(hist[-10:, 0].mean()) < 0.5 * float(hist[:5, 0].mean())                     # overfits the fixed batch
+
+
+@pytest.mark.parametrize("nc,S,B", [(80, 640, 64), (80, 1280, 16)])
+def test_full_size_configs_3_and_4(nc, S, B):
+    """BASELINE configs[2] / [3] at their stated per-GPU size (nc=80; 640x640 bs=64 and 1280x1280 bs=16), where the CPU
+    oracle would take many minutes: size-independent properties of ONE training step, fp32 first, then bf16:
+      (i) each path is bitwise reproducible run to run (fixed-order reductions in every kernel variant these sizes select);
+      (ii) the bf16 path agrees with the fp32 path (itself pinned to the oracle at reduced size) within the stated bf16
+           tolerances of this file: loss terms 1 %, global gradient norm 5 %, weight-gradient cosine >= 0.90;
+      (iii) everything is finite and the BatchNorm running statistics moved."""
+    y = api()
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(31)).cuda()
+    tg = [t.cuda() for t in y.synthetic_targets(B, nc, S, 8, 32)]
+
+    def run(dtype):
+        torch.manual_seed(0)
+        m = y.YOLO(num_classes=nc, img_size=S).cuda()
+        tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0, dtype=dtype)
+        loss = tr.step(x, tg)[:4].cpu().clone()
+        res = (loss, tr.flat_g.clone(), float(tr.norm), m.stem[1].running_mean.clone(),
+               {n: p.grad.detach().clone() for n, p in m.named_parameters() if n.endswith("conv.weight") and p.numel() >= 4096})
+        del tr, m
+        torch.cuda.empty_cache()
+        return res
+
+    f_a, f_b = run("f32"), run("f32")
+    assert torch.equal(f_a[0], f_b[0]) and torch.equal(f_a[1], f_b[1])
+    del f_b
+    h_a, h_b = run("bf16"), run("bf16")
+    assert torch.equal(h_a[0], h_b[0]) and torch.equal(h_a[1], h_b[1])
+    del h_b
+    for r in (f_a, h_a):
+        assert torch.isfinite(r[0]).all() and torch.isfinite(r[1]).all() and float(r[3].abs().max()) > 0
+    np.testing.assert_allclose(h_a[0].numpy(), f_a[0].numpy(), rtol=LOSS_RTOL, atol=1e-5)
+    assert abs(h_a[2] - f_a[2]) <= 0.05 * f_a[2]
+    cf, ch = min(1.0, 10.0 / (f_a[2] + 1e-6)), min(1.0, 10.0 / (h_a[2] + 1e-6))
+    checked = 0
+    for n, gf in f_a[4].items():
+        a, b = (h_a[4][n].reshape(-1).double() / ch), (gf.reshape(-1).double() / cf)
+        if float(b.norm()) < 1e-3 * f_a[2]:
+            continue
+        assert float(a @ b / (a.norm() * b.norm() + 1e-30)) >= COS_MIN, n
+        checked += 1
+    assert checked >= 30

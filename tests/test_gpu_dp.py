@@ -92,7 +92,11 @@ def test_two_rank_trainer_matches_oracle_on_shards(tmp_path):
     # well above the fp32 noise floor (Adam's first step is lr * g / (|g| + eps): a noise-level gradient moves +-lr in an
     # implementation-dependent direction, see test_gpu_model.py)
     checked = 0
+    q2 = {"stem.0.bias", "stem.3.bias", "backbone_p3.1.bias", "backbone_p4.0.bias", "backbone_p5.0.bias", "sppf.conv1.bias",
+          "sppf.conv2.bias"}        # conv biases cancelled by the following BatchNorm: their gradient is rounding noise (quirk Q2)
     for (o, n_el), n in zip(spans, names):
+        if n in q2:
+            continue
         g1 = mean1[n].reshape(-1)
         strong = g1.abs() > 1e-2 * max(float(g1.abs().max()), 1e-12)
         d_got = (res[0]["p_steps"][0][o:o + n_el] - flat0[o:o + n_el])[strong]

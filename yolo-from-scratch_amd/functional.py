@@ -105,13 +105,15 @@ def ciou_loss(pred_boxes, target_boxes, eps=1e-7):
 
 # ------------------------------------------------------------------------------------------------
 def run_loss_kernel(preds: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], dpreds, anchors18, grids, B, nc,
-                    loss_w, grad_w, out: torch.Tensor, ws: torch.Tensor, stream: int):
-    """Thin typed call of yh_yolo_loss; preds/targets/dpreds are 3-slot lists (None = absent)."""
-    L.check(L.lib().yh_yolo_loss(L.ptr3(preds), L.ptr3(targets), L.ptr3(dpreds) if dpreds is not None else None,
-                                 L.floats(anchors18), L.int3(grids), B, nc, LOSS_IMG_SIZE,
-                                 L.floats(loss_w) if loss_w is not None else None,
-                                 L.floats(grad_w) if grad_w is not None else None,
-                                 out.data_ptr(), ws.data_ptr(), stream), "yolo_loss")
+                    loss_w, grad_w, out: torch.Tensor, ws: torch.Tensor, stream: int, dpred_bf16: bool = False, dpred_ld=None):
+    """Thin typed call of yh_yolo_loss(_ex); preds/targets/dpreds are 3-slot lists (None = absent).  dpred_bf16 /
+    dpred_ld: the bf16 path's head gradient (bf16, pixel rows padded to a multiple of 8 channels)."""
+    L.check(L.lib().yh_yolo_loss_ex(L.ptr3(preds), L.ptr3(targets), L.ptr3(dpreds) if dpreds is not None else None,
+                                    int(bool(dpred_bf16)), L.int3(dpred_ld) if dpred_ld is not None else None,
+                                    L.floats(anchors18), L.int3(grids), B, nc, LOSS_IMG_SIZE,
+                                    L.floats(loss_w) if loss_w is not None else None,
+                                    L.floats(grad_w) if grad_w is not None else None,
+                                    out.data_ptr(), ws.data_ptr(), stream), "yolo_loss")
 
 
 class _YoloLoss(torch.autograd.Function):

@@ -30,19 +30,28 @@ def _rup4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
-class Buffer:
-    """An NHWC fp32 activation tensor (B,H,W,C) plus, lazily, its gradient tensor."""
+def _rup8(c: int) -> int:
+    return (c + 7) // 8 * 8
 
-    def __init__(self, plan: "Plan", B: int, H: int, W: int, C: int, name: str):
+
+class Buffer:
+    """An NHWC activation tensor (B,H,W,C) -- fp32, or bf16 on the bf16 path -- plus, lazily, its gradient tensor.
+    The gradient may have its own type and pixel stride: the bf16 path's head outputs stay fp32 (they feed the fp32
+    loss) while their gradient is bf16 with the channel axis zero-padded to a multiple of 8 (grad_C)."""
+
+    def __init__(self, plan: "Plan", B: int, H: int, W: int, C: int, name: str, dtype: Optional[torch.dtype] = None,
+                 grad_C: Optional[int] = None):
         self.plan, self.B, self.H, self.W, self.C, self.name = plan, B, H, W, C, name
-        self.data = torch.empty(B, H, W, C, device=plan.device, dtype=torch.float32)
+        self.dtype = dtype if dtype is not None else plan.act_dtype
+        self.grad_dtype, self.grad_C = plan.act_dtype, (grad_C if grad_C is not None else C)
+        self.data = torch.empty(B, H, W, C, device=plan.device, dtype=self.dtype)
         self._grad: Optional[torch.Tensor] = None
         self.grad_cover: List[Tuple[int, int]] = []   # channel ranges already written in this backward
 
     @property
     def grad(self) -> torch.Tensor:
-        if self._grad is None:
-            self._grad = torch.empty_like(self.data)
+        if self._grad is None:      # zeros: padding channels of a padded gradient must stay finite (they meet zero weights)
+            self._grad = torch.zeros(self.B, self.H, self.W, self.grad_C, device=self.plan.device, dtype=self.grad_dtype)
         return self._grad
 
     def view(self, off: int = 0, C: Optional[int] = None) -> "View":
@@ -64,9 +73,11 @@ class View:
     @property
     def ld(self): return self.buf.C
     @property
+    def ldg(self): return self.buf.grad_C
+    @property
     def M(self): return self.buf.B * self.buf.H * self.buf.W
-    def ptr(self) -> int: return self.buf.data.data_ptr() + 4 * self.off
-    def gptr(self) -> int: return self.buf.grad.data_ptr() + 4 * self.off
+    def ptr(self) -> int: return self.buf.data.data_ptr() + self.buf.data.element_size() * self.off
+    def gptr(self) -> int: return self.buf.grad.data_ptr() + self.buf.grad.element_size() * self.off
 
 
 @dataclass
@@ -127,13 +138,21 @@ class SyncRec:
 class Plan:
     """Trace target + compiled op lists for one module at one input shape / mode."""
 
-    def __init__(self, device: torch.device, in_shape: Tuple[int, int, int, int], training: bool, need_input_grad: bool):
+    def __init__(self, device: torch.device, in_shape: Tuple[int, int, int, int], training: bool, need_input_grad: bool,
+                 dtype: str = "f32"):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
+        if dtype == "bf16" and not training:
+            raise NotImplementedError("the bf16 path covers training plans; eval plans run the fp32 fused kernels")
         self.device, self.training, self.need_input_grad = device, training, need_input_grad
+        self.dtype = dtype
+        self.bf16 = dtype == "bf16"
+        self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
         self.B, self.Cimg, self.Himg, self.Wimg = in_shape
         self.recs: List[object] = []
         self.buffers: List[Buffer] = []
         self.outputs: List[Tuple[View, str]] = []       # (view, "nhwc_heads" | "nchw")
-        self.input = self.new_buffer(self.B, self.Himg, self.Wimg, _rup4(self.Cimg), "input")
+        self.input = self.new_buffer(self.B, self.Himg, self.Wimg, (_rup8 if self.bf16 else _rup4)(self.Cimg), "input")
         self.generation = 0
         self.lane = 0                      # lane given to records traced from now on (see side_lane())
         self.fwd_ops = self.bwd_ops = None
@@ -142,8 +161,8 @@ class Plan:
         self._grad_of = None
 
     # ---- tracing API used by the modules ------------------------------------------------------
-    def new_buffer(self, B, H, W, C, name="act") -> Buffer:
-        b = Buffer(self, B, H, W, C, name)
+    def new_buffer(self, B, H, W, C, name="act", dtype=None, grad_C=None) -> Buffer:
+        b = Buffer(self, B, H, W, C, name, dtype, grad_C)
         self.buffers.append(b)
         return b
 
@@ -155,15 +174,25 @@ class Plan:
             raise NotImplementedError(f"HIP conv path supports square k in (1,3), stride in (1,2), padding k//2; got {conv}")
         if (k, s) == (1, 2):
             raise NotImplementedError("1x1 stride-2 convolutions are not part of this network")
-        if conv.in_channels != x.C and _rup4(conv.in_channels) != x.C:
+        if conv.in_channels != x.C and (_rup8 if self.bf16 else _rup4)(conv.in_channels) != x.C:
             raise ValueError(f"conv expects {conv.in_channels} input channels, got a view with {x.C}")
+        if self.bf16 and (x.C % 8 or x.ld % 8 or x.off % 8 or (bn is not None and conv.out_channels % 8)):
+            raise NotImplementedError("the bf16 path needs channel counts, views and strides in multiples of 8")
         Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
         cout = conv.out_channels
         if bn is not None and cout % 4:
             raise NotImplementedError("Conv+BN+SiLU on the HIP path needs out_channels % 4 == 0")
         f = 2 if upsample else 1
+        if out is None and self.bf16 and bn is None:
+            # a plain conv output on the bf16 path (the detection heads): fp32 values for the fp32 loss, bf16 gradient
+            # with the channel axis zero-padded to a multiple of 8 (the backward GEMMs read 16-byte pieces)
+            out = self.new_buffer(x.B, Ho * f, Wo * f, cout, "head", dtype=torch.float32, grad_C=_rup8(cout)).view()
         if out is None:
             out = self.new_buffer(x.B, Ho * f, Wo * f, cout if bn is None else _rup4(cout)).view()
+        if self.bf16 and bn is not None and (out.off % 8 or out.ld % 8):
+            raise NotImplementedError("the bf16 path needs output views aligned to 8 channels")
+        if self.bf16 and bn is None and out.buf.dtype != torch.float32:
+            raise NotImplementedError("plain conv outputs on the bf16 path are fp32 head tensors")
         if (out.H, out.W, out.C) != (Ho * f, Wo * f, cout):
             raise ValueError(f"output view {(out.H, out.W, out.C)} does not match conv result {(Ho * f, Wo * f, cout)}")
         if residual is not None and (residual.H, residual.W, residual.C) != (Ho, Wo, cout):
@@ -219,6 +248,8 @@ class Plan:
         receives its gradient (views of a flat buffer); required when training."""
         lib = L.lib()
         dev = self.device
+        if self.bf16:
+            return self._compile_bf16(grad_of)
         f32 = dict(device=dev, dtype=torch.float32)
         fwd: List[L.YhOp] = []
         keep: List[torch.Tensor] = []          # tensors referenced only through raw pointers
@@ -416,6 +447,156 @@ class Plan:
         self._keep = keep
         self._grad_of = grad_of
         self.param_ptrs = self._signature()
+
+    # ---- bf16 lowering (BASELINE configs 3-4) -------------------------------------------------------------------------
+    def _compile_bf16(self, grad_of):
+        """One kernel family for every convolution: yh_bf16_conv_fwd / _bwd_data / _bwd_weight (bf16 operands, fp32
+        accumulation), bf16 BN+SiLU / pool passes, fp32 statistics and parameter gradients."""
+        import struct
+        lib = L.lib()
+        dev = self.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        b16 = dict(device=dev, dtype=torch.bfloat16)
+        fwd: List[L.YhOp] = []
+        keep: List[torch.Tensor] = []
+        packs: List[tuple] = []
+        # sibling pointwise convs (C3 conv1 / conv2): one backward-data GEMM over K = Cout1 + Cout2, dx written once
+        if os.environ.get("YH_PAIR_DGRAD", "1") != "0":
+            groups: Dict[tuple, List[ConvRec]] = {}
+            for r in self.recs:
+                if isinstance(r, ConvRec) and r.k == 1 and r.s == 1 and r.bn is not None and r.cout % 8 == 0:
+                    groups.setdefault((id(r.x.buf), r.x.off, r.x.C), []).append(r)
+            for grp in groups.values():
+                if len(grp) == 2 and grp[0].cout == grp[1].cout and (self.need_input_grad or grp[0].x.buf is not self.input):
+                    grp[0].pair, grp[1].pair = grp[1], grp[0]
+                    grp[0].pair_first = True
+        for r in self.recs:
+            if isinstance(r, SyncRec):
+                fwd.append(_op(L.OP_FORK if r.kind == "fork" else L.OP_JOIN))
+                continue
+            ln = r.lane
+            if isinstance(r, PoolRec):
+                r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
+                fwd.append(_op(L.OP_BF16_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
+                               i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C], lane=ln))
+                continue
+            kk = r.k * r.k
+            cin_real = r.weight.shape[1]
+            r.need_dx = self.need_input_grad or r.x.buf is not self.input
+            r.ldwf, r.ldwb = _rup8(r.cout), _rup8(r.cin)
+            r.wf = torch.empty(kk * r.cin * r.ldwf, **b16)
+            kpad = _rup8(r.cout)
+            koff = 0
+            if r.need_dx:
+                if r.pair is not None:
+                    kpad = r.cout + r.pair.cout
+                    if r.pair_first:
+                        r.wb = r.pair.wb = torch.zeros(kpad * r.ldwb, **b16)
+                    else:
+                        koff = r.pair.cout
+                else:
+                    r.wb = torch.zeros(kk * kpad * r.ldwb, **b16)
+            packs.append((r.weight.data_ptr(), r.wf.data_ptr(), r.wb.data_ptr() if r.need_dx else 0, r.cout, cin_real, kk,
+                          r.cin, r.ldwf, r.ldwb, koff, kpad))
+            M = r.x.B * r.Ho * r.Wo
+            r.nblk = lib.yh_bf16_conv_blocks(M)
+            if r.bn is not None:
+                r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **b16)
+                r.coef = torch.empty(4 * r.cout, **f32)
+                r.part = torch.empty(max(r.nblk, lib.yh_bn_bwd_blocks(M, r.cout)) * 2 * r.cout, **f32)
+                fwd.append(_op(L.OP_BF16_CONV_FWD, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part],
+                               i=[r.x.ld, r.ldwf, r.cout, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, 0], lane=ln))
+                track = r.bn.track_running_stats and r.bn.running_mean is not None
+                mom = r.bn.momentum if r.bn.momentum is not None else 0.1
+                fwd.append(_op(L.OP_BN_FINALIZE,
+                               p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
+                                  r.bn.running_var if track else None, r.coef, r.bn.num_batches_tracked if track else None],
+                               i=[r.nblk, r.cout], f=[mom, r.bn.eps], l=[M], lane=ln))
+                fwd.append(_op(L.OP_BF16_BN_SILU_FWD,
+                               p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
+                               i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo, int(r.upsample)],
+                               l=[M], lane=ln))
+            else:       # head output: fp32, no BatchNorm
+                fwd.append(_op(L.OP_BF16_CONV_FWD, p=[r.x.ptr(), r.wf, r.bias, r.out.ptr(), None],
+                               i=[r.x.ld, r.ldwf, r.out.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, 1], lane=ln))
+        blob = b"".join(struct.pack("<QQQiiiiiiii", *d) for d in packs)
+        self.pack_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        fwd.insert(0, _op(L.OP_BF16_PACK_MULTI, p=[self.pack_table], i=[len(packs)]))
+        self.fwd_ops = _pack(fwd)
+        self.bwd_ops = _pack(self._lower_backward_bf16(grad_of))
+        self._keep = keep
+        self._grad_of = grad_of
+        self.param_ptrs = self._signature()
+
+    def _lower_backward_bf16(self, grad_of) -> List[L.YhOp]:
+        lib = L.lib()
+        if grad_of is None:
+            raise ValueError("training plan needs gradient destinations")
+        for b in self.buffers:
+            b.grad_cover = []
+        for v, _ in self.outputs:
+            v.buf.grad_cover.append((v.off, v.off + v.C))
+        ws_floats = 1
+        for r in self.recs:
+            if isinstance(r, ConvRec):
+                ws_floats = max(ws_floats, lib.yh_bf16_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
+                if r.bias is not None:
+                    ws_floats = max(ws_floats, lib.yh_colsum_ws(r.x.B * r.Ho * r.Wo, r.cout))
+        self.ws = torch.empty(int(ws_floats), device=self.device, dtype=torch.float32)
+        ops: List[L.YhOp] = []
+        pair_pending = set()
+        self.grad_ready = {}
+        for r in reversed(self.recs):
+            if isinstance(r, SyncRec):
+                continue
+            if isinstance(r, PoolRec):
+                dst, acc = self._grad_target(r.x)
+                if not acc:
+                    raise NotImplementedError("max-pool backward expects an already written input gradient")
+                ops.append(_op(L.OP_BF16_MAXPOOL5_BWD, p=[r.out.gptr(), r.arg, dst], i=[r.out.ldg, r.x.ldg, r.x.B, r.x.H, r.x.W, r.x.C]))
+                continue
+            M = r.x.B * r.Ho * r.Wo
+            if r.bn is not None:
+                nb = lib.yh_bn_bwd_blocks(M, r.cout)
+                ops.append(_op(L.OP_BF16_BN_SILU_BWD_REDUCE, p=[r.out.gptr(), r.y, r.coef, r.part],
+                               i=[r.out.ldg, r.cout, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                if r.residual is not None:
+                    dres, racc = self._grad_target(r.residual)
+                    ldres = r.residual.ldg
+                else:
+                    dres, racc, ldres = None, 0, 0
+                ops.append(_op(L.OP_BF16_BN_SILU_BWD_APPLY,
+                               p=[r.out.gptr(), r.y, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)], grad_of[id(r.bn.bias)],
+                                  r.y, dres],
+                               i=[r.out.ldg, r.cout, nb, r.cout, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                dy, lddy, kcout = r.y.data_ptr(), r.cout, r.cout
+                self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
+            else:       # head: the loss wrote a bf16 gradient zero-padded to a multiple of 8 channels
+                dy, lddy, kcout = r.out.gptr(), r.out.ldg, _rup8(r.cout)
+                if r.out.off != 0 or r.out.ldg != kcout:
+                    raise NotImplementedError("head gradient must own its (padded) buffer")
+            if r.bias is not None:
+                ops.append(_op(L.OP_BF16_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
+                self.grad_ready[id(r.bias)] = len(ops)
+            ops.append(_op(L.OP_BF16_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+                           i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s], l=[self.ws.numel()]))
+            self.grad_ready[id(r.weight)] = len(ops)
+            if not r.need_dx:
+                continue
+            if r.pair is not None:
+                if id(r.pair) in pair_pending:      # second of the pair in backward order: both dY are final now
+                    first, second = (r, r.pair) if r.pair_first else (r.pair, r)
+                    dst, acc = self._grad_target(r.x)
+                    ops.append(_op(L.OP_BF16_CONV_BWD_DATA, p=[first.y, first.wb, dst, second.y],
+                                   i=[first.cout, first.ldwb, r.x.ldg, r.x.B, r.x.H, r.x.W, r.cin, first.cout + second.cout, 1, 1,
+                                      acc, first.cout]))
+                else:
+                    pair_pending.add(id(r))
+                continue
+            dst, acc = self._grad_target(r.x)
+            ops.append(_op(L.OP_BF16_CONV_BWD_DATA, p=[dy, r.wb, dst, None],
+                           i=[lddy, r.ldwb, r.x.ldg, r.x.B, r.x.H, r.x.W, r.cin, kcout, r.k, r.s, acc, 0]))
+        return ops
 
     def _grad_target(self, v: View) -> Tuple[int, int]:
         """Pointer into the gradient tensor of `v` and whether the op must accumulate."""

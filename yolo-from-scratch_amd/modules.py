@@ -68,6 +68,17 @@ class HipModule(nn.Module):
         self._plans: Dict[tuple, Plan] = {}
         self._flat_grad: Optional[torch.Tensor] = None
         self._flat_views: Dict[int, torch.Tensor] = {}
+        self._compute_dtype = "f32"
+
+    def set_compute_dtype(self, dtype: str):
+        """'f32' (default: the reference's arithmetic) or 'bf16' (BASELINE configs 3-4): TRAINING plans then keep
+        activations, activation gradients and per-step weight packs in bf16 and run the convolutions on the bf16 MFMA;
+        master weights, accumulators, BatchNorm statistics, the loss and all parameter gradients stay fp32.  Eval-mode
+        forwards always run the fp32 fused kernels.  The module interface (fp32 NCHW in / fp32 out) does not change."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
+        self._compute_dtype = dtype
+        return self
 
     # -- to be provided by subclasses ------------------------------------------------------------
     def _emit(self, g: Plan, x: View, out: Optional[View] = None) -> View:
@@ -101,13 +112,14 @@ class HipModule(nn.Module):
         need_dx = bool(x.requires_grad and torch.is_grad_enabled())
         training = bool(self.training)
         shape = tuple(x.shape) if x.dtype == torch.float32 else (x.shape[0], x.shape[3], x.shape[1], x.shape[2])
-        key = (shape, training, need_dx, x.device.index)
+        dtype = self._compute_dtype if training else "f32"
+        key = (shape, training, need_dx, x.device.index, dtype)
         views = self._grad_views(x.device)
         plan = self._plans.get(key)
         if plan is not None and plan.params_moved():
             plan = None
         if plan is None:
-            plan = Plan(x.device, shape, training, need_dx)
+            plan = Plan(x.device, shape, training, need_dx, dtype)
             self._trace(plan)
             plan.compile(views if training else None)
             self._plans[key] = plan
@@ -130,22 +142,23 @@ class HipModule(nn.Module):
     def _load_input(self, plan: Plan, x: torch.Tensor):
         x = x.contiguous()
         buf = plan.input
+        lib = L.lib()
         if x.dtype == torch.uint8:      # (B,H,W,3) image bytes straight from the loader: /255 on the device
             B, H, W, C = x.shape
-            L.check(L.lib().yh_u8hwc_to_nhwc(x.data_ptr(), buf.data.data_ptr(), B, H, W, C, buf.C, buf.C, _stream(x.device)),
-                    "u8hwc_to_nhwc")
+            fn = lib.yh_bf16_u8hwc_to_nhwc if plan.bf16 else lib.yh_u8hwc_to_nhwc
+            L.check(fn(x.data_ptr(), buf.data.data_ptr(), B, H, W, C, buf.C, buf.C, _stream(x.device)), "u8hwc_to_nhwc")
             return
         B, C, H, W = x.shape
-        L.check(L.lib().yh_nchw_to_nhwc(x.data_ptr(), buf.data.data_ptr(), B, C, H, W, buf.C, buf.C, _stream(x.device)),
-                "nchw_to_nhwc")
+        fn = lib.yh_bf16_nchw_to_nhwc if plan.bf16 else lib.yh_nchw_to_nhwc
+        L.check(fn(x.data_ptr(), buf.data.data_ptr(), B, C, H, W, buf.C, buf.C, _stream(x.device)), "nchw_to_nhwc")
 
     def _collect_outputs(self, plan: Plan) -> List[torch.Tensor]:
         outs = []
         for v, kind in plan.outputs:
             if kind == "nchw":
                 t = torch.empty(v.B, v.C, v.H, v.W, device=plan.device, dtype=torch.float32)
-                L.check(L.lib().yh_nhwc_to_nchw(v.ptr(), t.data_ptr(), v.B, v.C, v.H, v.W, v.ld, 0, _stream(plan.device)),
-                        "nhwc_to_nchw")
+                fn = L.lib().yh_bf16_nhwc_to_nchw if v.buf.dtype == torch.bfloat16 else L.lib().yh_nhwc_to_nchw
+                L.check(fn(v.ptr(), t.data_ptr(), v.B, v.C, v.H, v.W, v.ld, 0, _stream(plan.device)), "nhwc_to_nchw")
             else:   # head output: the NHWC buffer *is* (B,G,G,3,5+nc)
                 t = v.buf.data.view(v.B, v.H, v.W, 3, v.C // 3).clone()
             outs.append(t)
@@ -155,22 +168,23 @@ class HipModule(nn.Module):
         st = _stream(plan.device)
         for (v, kind), g in zip(plan.outputs, gouts):
             if g is None:
-                L.check(L.lib().yh_memset(v.buf.grad.data_ptr(), 0, v.buf.grad.numel() * 4, st), "memset")
+                L.check(L.lib().yh_memset(v.buf.grad.data_ptr(), 0, v.buf.grad.numel() * v.buf.grad.element_size(), st), "memset")
                 continue
-            g = g.contiguous()
+            g = g.contiguous().float()
             if kind == "nchw":
                 if v.off != 0 or v.ld != v.C:
                     raise NotImplementedError("output gradient into a channel slice")
-                L.check(L.lib().yh_nchw_to_nhwc(g.data_ptr(), v.buf.grad.data_ptr(), v.B, v.C, v.H, v.W, v.ld, v.C, st),
-                        "nchw_to_nhwc(grad)")
-            else:
-                v.buf.grad.view(-1).copy_(g.reshape(-1))
+                fn = L.lib().yh_bf16_nchw_to_nhwc if plan.bf16 else L.lib().yh_nchw_to_nhwc
+                L.check(fn(g.data_ptr(), v.buf.grad.data_ptr(), v.B, v.C, v.H, v.W, v.ldg, v.C, st), "nchw_to_nhwc(grad)")
+            else:       # head gradient: (B,G,G,3,5+nc) -> the buffer's (possibly padded, possibly bf16) pixel rows
+                v.buf.grad[..., :v.C].copy_(g.reshape(v.B, v.H, v.W, v.C))
 
     def _input_grad(self, plan: Plan) -> torch.Tensor:
         buf = plan.input
         gx = torch.empty(plan.B, plan.Cimg, plan.Himg, plan.Wimg, device=plan.device, dtype=torch.float32)
-        L.check(L.lib().yh_nhwc_to_nchw(buf.grad.data_ptr(), gx.data_ptr(), plan.B, plan.Cimg, plan.Himg, plan.Wimg,
-                                        buf.C, 0, _stream(plan.device)), "nhwc_to_nchw(grad)")
+        fn = L.lib().yh_bf16_nhwc_to_nchw if plan.bf16 else L.lib().yh_nhwc_to_nchw
+        L.check(fn(buf.grad.data_ptr(), gx.data_ptr(), plan.B, plan.Cimg, plan.Himg, plan.Wimg, buf.grad_C, 0,
+                   _stream(plan.device)), "nhwc_to_nchw(grad)")
         return gx
 
 

@@ -90,8 +90,11 @@ class HipTrainer:
     """Owns the flat parameter / gradient / Adam-state buffers of a YOLO model and runs fused steps."""
 
     def __init__(self, model: HipModule, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = 10.0,
-                 process_group=None, n_buckets: int = 4):
+                 process_group=None, n_buckets: int = 4, dtype: Optional[str] = None):
+        """dtype: None keeps the model's compute dtype; 'bf16' / 'f32' set it (HipModule.set_compute_dtype)."""
         self.model = model
+        if dtype is not None:
+            model.set_compute_dtype(dtype)
         params = list(model.parameters())
         if not params or not params[0].is_cuda:
             raise RuntimeError("HipTrainer: move the model to the GPU first; there is no CPU fallback")
@@ -153,7 +156,7 @@ class HipTrainer:
         plan.run_forward(st)
         run_loss_kernel([v.buf.data for v in heads], targets, [v.buf.grad for v in heads],
                         _anchors18(model.anchors), [v.H for v in heads], plan.B, nc, None, None, self.loss_out,
-                        self._loss_ws, st)
+                        self._loss_ws, st, dpred_bf16=plan.bf16, dpred_ld=[v.ldg for v in heads] if plan.bf16 else None)
         begin = 0
         for end, rng in self._segments[1]:
             plan.run_backward(st, begin, end)       # yh_run joins its side stream before returning
