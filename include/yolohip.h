@@ -81,10 +81,13 @@ int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s);
 int yh_conv_fwd_fused(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res, int ldr,
                       float *y, int ldy, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int act_silu,
                       int upsample, void *stream);
-/* Small-M (batch-1 inference) form of yh_conv_fwd_fused: when a 3x3 layer would launch fewer than 256 workgroups its
- * taps are split over four partial GEMMs in ONE launch (workspace slabs, ws_floats >= yh_conv_fwd_fused_ws(...)), then
- * a finish kernel adds the slabs in fixed order and applies bias / SiLU / residual / upsample.  With ws == NULL or a layer
- * the heuristic leaves alone (yh_conv_fwd_fused_ws == 0) it is yh_conv_fwd_fused. */
+/* Small-M (batch-1 inference) form of yh_conv_fwd_fused: when a layer would launch few workgroups its K axis (taps x
+ * channels) is split over S workgroups per output tile INSIDE ONE launch; partial tiles go to fp32 slabs in ws and the
+ * last workgroup to arrive at a tile (agent-scope ticket) adds them in fixed order and applies bias / SiLU / residual /
+ * upsample -- deterministic, no second launch.  ws_floats >= yh_conv_fwd_fused_ws(...) = S*M*ld slab floats followed by
+ * one int32 ticket per tile; the TICKETS MUST BE ZERO before the first call (the reducer leaves them zero), and one ws
+ * must not be shared by launches that can run concurrently.  With ws == NULL or a layer the heuristic leaves alone
+ * (yh_conv_fwd_fused_ws == 0) it is yh_conv_fwd_fused. */
 int yh_conv_fwd_fused_splitk(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res, int ldr,
                              float *y, int ldy, float *ws, int64_t ws_floats, int B, int Hi, int Wi, int Cin, int Cout, int k,
                              int s, int act_silu, int upsample, void *stream);
@@ -93,6 +96,19 @@ int64_t yh_conv_fwd_fused_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, in
  * DEVICE array of 88-byte records { const float *oihw, *bias_in, *gamma, *beta, *running_mean, *running_var;
  * float *wf, *bias_out; int32 Cout, Cin, k*k, cin_pad, ldwf; float eps } (gamma == NULL: plain pack + bias copy). */
 int yh_pack_fold_multi(const void *table, int n_layers, void *stream);
+/* Eval-mode BatchNorm folded into plain OIHW weights + a bias (the input of yh_pack_weights_multi / yh_wino_weights_multi /
+ * yh_pw_pack_multi, so every forward kernel family can run the folded layer).  `table`: DEVICE array of 80-byte records
+ * { const float *oihw, *bias_in, *gamma, *beta, *running_mean, *running_var; float *oihw_out, *bias_out; int32 Cout,
+ * Cin*k*k; float eps; int32 0 } (gamma == NULL: copy). */
+int yh_fold_oihw_multi(const void *table, int n_layers, void *stream);
+/* Inference forms of the Winograd / pointwise forward kernels: y = [upsample x2]( silu(conv(x) + bias) + residual ) with
+ * folded weights (yh_fold_oihw_multi -> yh_wino_weights_multi / yh_pw_pack_multi); same eligibility rules as
+ * yh_conv_wino_fwd / yh_conv_pw_fwd.  For large batches (eval_epoch, predict_batch); batch-1 latency uses
+ * yh_conv_fwd_fused_splitk.  replaces: the same call sites as yh_conv_fwd_fused (train.py:1130-1141, 960-1032). */
+int yh_conv_wino_fwd_fused(const float *x, int ldx, const float *U, int ldu, const float *bias, const float *res, int ldr, float *y,
+                           int ldy, int B, int H, int W, int Cin, int Cout, int act_silu, int upsample, void *stream);
+int yh_conv_pw_fwd_fused(const float *x, int ldx, const float *wq, int ldw, const float *bias, const float *res, int ldr, float *y,
+                         int ldy, int B, int H, int W, int Cin, int Cout, int act_silu, int upsample, void *stream);
 /* Backward-data: dx (+)= conv_transpose(dy, w).  replaces: aten::convolution_backward (input
  * gradient) reached from loss.backward() (train.py:913). */
 int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi,
@@ -373,7 +389,8 @@ enum {
     /* bf16 path: argument slots as in the fp32 op of the same name unless noted in api.hip */
     YH_OP_BF16_PACK_MULTI, YH_OP_BF16_CONV_FWD, YH_OP_BF16_CONV_BWD_DATA, YH_OP_BF16_CONV_BWD_WEIGHT, YH_OP_BF16_COLSUM,
     YH_OP_BF16_BN_SILU_FWD, YH_OP_BF16_BN_SILU_BWD_REDUCE, YH_OP_BF16_BN_SILU_BWD_APPLY, YH_OP_BF16_MAXPOOL5_FWD,
-    YH_OP_BF16_MAXPOOL5_BWD
+    YH_OP_BF16_MAXPOOL5_BWD,
+    YH_OP_FOLD_OIHW_MULTI, YH_OP_CONV_WINO_FWD_FUSED, YH_OP_CONV_PW_FWD_FUSED   /* slots of YH_OP_CONV_FWD_FUSED */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

@@ -12,8 +12,7 @@ places) and the tests measure its drift next to the HIP path's:
     objectness gradient is almost constant over 10^5..10^6 cells), so 0.2 % storage noise becomes cosines of ~0.995
     (heads), ~0.985 (neck) and ~0.95 (backbone, behind the max-pools whose argmax ties multiply in bf16) against fp32 --
     in the emulation.  The HIP path must reach the emulation's cosine minus 0.03 on every tensor, and 0.90 absolutely
-    (slack 0.06 and no absolute floor for the 64..256-entry BatchNorm vectors: a noisier statistic, and a few of them are
-    noise-dominated at initialisation in the emulation as well);
+    (0.06 / 0.85, and 20 % instead of 10 % on the norm, for the 64..256-entry BatchNorm vectors: noisier statistics);
   * the global gradient norm within 5 %.
 The seven conv biases in front of BatchNorm (quirk Q2: true gradient 0) are excluded as in the fp32 tests."""
 import numpy as np
@@ -79,11 +78,9 @@ def test_bf16_step_tracks_fp32_oracle(nc, S, B):
         g_got = params[n].grad.detach().cpu().reshape(-1).double() / coef
         c_hip, c_emu = _cos(g_ref, g_got), _cos(g_ref, G["bf16"][n])
         small = g_ref.numel() < 1024          # BatchNorm vectors (64..256 entries): a noisier statistic, twice the slack
-        # (a few BatchNorm vectors have a noise-dominated gradient at initialisation under ANY bf16 storage -- the emulation
-        # itself drops to ~0.2 there -- so the absolute floor is applied to the large weight tensors only)
         assert c_hip >= c_emu - COS_SLACK * (2 if small else 1), (n, c_hip, c_emu)
-        assert small or c_hip >= COS_FLOOR, (n, c_hip, c_emu)
-        assert abs(float(g_got.norm()) - nr) <= NORM_RTOL * nr, (n, float(g_got.norm()), nr)
+        assert c_hip >= COS_FLOOR - (0.05 if small else 0.0), (n, c_hip, c_emu)
+        assert abs(float(g_got.norm()) - nr) <= NORM_RTOL * (2 if small else 1) * nr, (n, float(g_got.norm()), nr)
         worst = min(worst, c_hip)
         checked += 1
     assert checked >= 40

@@ -185,6 +185,51 @@ def test_eval_mode_forward_and_predict_pipeline(tmp_path):
                 assert y.compute_iou_corners(dets[i], dets[j]) <= 0.4 + 1e-6
 
 
+def test_eval_fast_kernels_match_oracle_and_generic_path(monkeypatch):
+    """Eval plans at batch sizes that fill the chip route 3x3 stride-1 layers to the Winograd kernel and 1x1 layers to the
+    pointwise GEMM, both with the folded-BatchNorm + bias + SiLU (+residual, +upsample) epilogue; the rest stays on the
+    gather-GEMM (with in-launch split-K where M is small).  Same results as the CPU oracle's eval forward and as the
+    all-generic routing (YH_EVAL_FAST=0); weights are re-folded when they change."""
+    from yolo_from_scratch_amd import _lib as L
+    y = api()
+    nc, S, B = 2, 320, 16
+    torch.manual_seed(3)
+    m = y.YOLO(num_classes=nc, img_size=S)
+    with torch.no_grad():                                   # non-trivial running statistics and affine parameters
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.7, 1.3)
+                mod.bias.uniform_(-0.1, 0.1)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = orc.forward(P, x, nc, training=False)
+    m = m.cuda().eval()
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("YH_EVAL_FAST", fast)
+        m._plans.clear()
+        with torch.no_grad():
+            outs[fast] = [p.clone() for p in m(x.cuda())]
+        kinds = [op.kind for op in m._plan_for(x.cuda()).fwd_ops[0][: m._plan_for(x.cuda()).fwd_ops[1]]]
+        nw, npw = kinds.count(L.OP_CONV_WINO_FWD_FUSED), kinds.count(L.OP_CONV_PW_FWD_FUSED)
+        assert (nw >= 8 and npw >= 8 and kinds.count(L.OP_CONV_FWD_FUSED) >= 8) if fast == "1" else (nw == 0 and npw == 0)
+    for a, b, r in zip(outs["1"], outs["0"], ref):
+        scale = float(r.abs().max())
+        assert float((a.cpu() - r).abs().max()) < 1e-4 * max(scale, 1.0)
+        assert float((a - b).abs().max()) < 1e-4 * max(scale, 1.0)
+    # weights change (through torch: version counters; through the package's own kernels: the weights epoch) -> re-fold
+    monkeypatch.setenv("YH_EVAL_FAST", "1")
+    m._plans.clear()
+    with torch.no_grad():
+        before = [p.clone() for p in m(x.cuda())]
+        m.head_p3[0].conv.weight.mul_(1.5)
+        after = [p.clone() for p in m(x.cuda())]
+    assert not torch.equal(before[0], after[0]) and torch.equal(before[2], after[2])
+
+
 def test_cpu_tensor_is_rejected_loudly():
     y = api()
     m = y.ConvBlock(4, 8, 3, 1, 1)

@@ -31,7 +31,8 @@ class YhOp(C.Structure):
  OP_CONV_WINO_BWD_DATA, OP_CONV_WINO_BWD_WEIGHT, OP_CONV_PW_BWD_WEIGHT, OP_PW_PACK_MULTI, OP_CONV_PW_FWD,
  OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M, OP_CONV_PW_FWD2, OP_NOP,
  OP_BF16_PACK_MULTI, OP_BF16_CONV_FWD, OP_BF16_CONV_BWD_DATA, OP_BF16_CONV_BWD_WEIGHT, OP_BF16_COLSUM, OP_BF16_BN_SILU_FWD,
- OP_BF16_BN_SILU_BWD_REDUCE, OP_BF16_BN_SILU_BWD_APPLY, OP_BF16_MAXPOOL5_FWD, OP_BF16_MAXPOOL5_BWD) = range(1, 46)
+ OP_BF16_BN_SILU_BWD_REDUCE, OP_BF16_BN_SILU_BWD_APPLY, OP_BF16_MAXPOOL5_FWD, OP_BF16_MAXPOOL5_BWD,
+ OP_FOLD_OIHW_MULTI, OP_CONV_WINO_FWD_FUSED, OP_CONV_PW_FWD_FUSED) = range(1, 49)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -49,6 +50,9 @@ _SIGS = {
     "yh_conv_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_fold_multi": (i32, [c_fp, i32, c_fp]),
+    "yh_fold_oihw_multi": (i32, [c_fp, i32, c_fp]),
+    "yh_conv_wino_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_pw_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_wino_weights": (i32, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),

@@ -108,6 +108,14 @@ static int run_one(const yh_op &o, void *st) {
                                           (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], p[4], i[10], st);
         case YH_OP_NOP:
             return 0;
+        case YH_OP_FOLD_OIHW_MULTI:
+            return yh_fold_oihw_multi(p[0], i[0], st);
+        case YH_OP_CONV_WINO_FWD_FUSED:     /* slots of YH_OP_CONV_FWD_FUSED (k = 3, s = 1 implied) */
+            return yh_conv_wino_fwd_fused((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (const float *)p[3],
+                                          i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[11], i[12], st);
+        case YH_OP_CONV_PW_FWD_FUSED:       /* slots of YH_OP_CONV_FWD_FUSED (k = 1, s = 1 implied) */
+            return yh_conv_pw_fwd_fused((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (const float *)p[3],
+                                        i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[11], i[12], st);
         // ---- bf16 path ----------------------------------------------------------------------------------------------
         case YH_OP_BF16_PACK_MULTI:
             return yh_bf16_pack_multi(p[0], i[0], st);

@@ -38,6 +38,12 @@ struct GatherGemm {
     const float *res;     // inference epilogue: + residual (after the activation), ld = ldr
     int ldr, act, up2;    // act: 1 = SiLU on (acc + bias); up2: replicate each output pixel 2x2 (nearest upsample)
     int nblk_n;
+    // split-K (small-M inference layers, SK template flag): blockIdx.y = split, each split multiplies a contiguous range of
+    // K chunks into its fp32 slab sk_ws[split][M][sk_ldws]; the LAST split to arrive at a tile (agent-scope ticket in
+    // sk_cnt[tile], zero before the launch and reset by the reducer) adds the slabs in split order and runs the epilogue
+    int sk_splits, sk_ldws;
+    float *sk_ws;
+    int *sk_cnt;
     unsigned cin_magic;   // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, magic) for k < 2^16
     unsigned xo_magic, yo_magic;   // exact division of a pixel index < 2^31 by Xo / Yo (see fast_div)
     int xo_shift, yo_shift;
@@ -69,9 +75,10 @@ template <> struct Mfma<16> {
     static __device__ __forceinline__ int row(int r, int lh) { return 4 * lh + r; }
 };
 
-template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT>
+template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT, int SK = 0>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs) {
-    const GatherGemm &g = gs.c[NCLS == 1 ? 0 : blockIdx.y];
+    static_assert(!SK || NCLS == 1, "split-K launches carry one problem");
+    const GatherGemm &g = gs.c[(NCLS == 1 || SK) ? 0 : blockIdx.y];
     typedef Mfma<MT> MF;
     typedef typename MF::Acc Acc;
     constexpr int LG = 64 / MT;            // lane groups = physical k values one MFMA consumes per lane slot
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                          // [2][BM][LDA]
     float *Bs = smem + 2 * BM * LDA;           // [2][BK][BN]
-    int *tapt = (int *)(Bs + 2 * BK * BN);     // [3][9]
+    int *tapt = (int *)(Bs + 2 * BK * BN);     // [3][9] (+ the split-K "last arriver" flag at [27])
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -195,7 +202,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
 #pragma unroll
             for (int r = 0; r < MF::NR; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (g.Ktot + BK - 1) / BK;
+    const int nch_all = (g.Ktot + BK - 1) / BK;
+    // split-K: this workgroup owns chunks [cbeg, cbeg + nchunks) of the K axis
+    const int cbeg = SK ? (int)(((long long)nch_all * blockIdx.y) / g.sk_splits) : 0;
+    const int nchunks = SK ? (int)(((long long)nch_all * (blockIdx.y + 1)) / g.sk_splits) - cbeg : nch_all;
     const int lr = lane & (MT - 1), lh = lane / MT;
     auto compute = [&](int buf, int kvalid) {
         const float *a = As + buf * BM * LDA + (wm * TM * MT + lr) * LDA + 4 * lh;
@@ -221,20 +231,94 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
     };
     // software pipeline, prefetch distance 2: at step c the loads of chunk c+2 are issued, chunk c is
     // multiplied from LDS, then chunk c+1 (loaded one step earlier) is written to the other LDS buffer.
-    load_tiles(0, raA, rbA);
+    load_tiles(cbeg, raA, rbA);
     store_tiles(0, raA, rbA);
-    if (nchunks > 1) load_tiles(1, raB, rbB);
+    if (nchunks > 1) load_tiles(cbeg + 1, raB, rbB);
     __syncthreads();
     for (int c = 0; c < nchunks; c += 2) {
-        if (c + 2 < nchunks) load_tiles(c + 2, raA, rbA);
-        compute(0, g.Ktot - c * BK);
+        if (c + 2 < nchunks) load_tiles(cbeg + c + 2, raA, rbA);
+        compute(0, g.Ktot - (cbeg + c) * BK);
         if (c + 1 < nchunks) store_tiles(1, raB, rbB);
         __syncthreads();
         if (c + 1 >= nchunks) break;
-        if (c + 3 < nchunks) load_tiles(c + 3, raB, rbB);
-        compute(1, g.Ktot - (c + 1) * BK);
+        if (c + 3 < nchunks) load_tiles(cbeg + c + 3, raB, rbB);
+        compute(1, g.Ktot - (cbeg + c + 1) * BK);
         if (c + 2 < nchunks) store_tiles(0, raA, rbA);
         __syncthreads();
+    }
+
+    if (SK) {
+        // publish this split's partial tile, then the last arriver of the tile reduces (cdna guide section 5, "in-launch
+        // split-K reduction": plain slab stores, vmcnt drain, barrier, one agent-scope release + relaxed ticket; the
+        // reducer takes one agent-scope acquire and reads every slab with plain loads in split order -- deterministic)
+        float *slab = g.sk_ws + (size_t)blockIdx.y * g.M * g.sk_ldws;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < MF::NR; ++r) {
+                const int m = m0 + wm * TM * MT + i * MT + MF::row(r, lh);
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * MT + j * MT + lr;
+                    if (n < g.N) slab[(size_t)m * g.sk_ldws + n] = acc[i][j][r];
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(&g.sk_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == g.sk_splits - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&g.sk_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            tapt[27] = last;
+        }
+        __syncthreads();
+        if (!tapt[27]) return;
+        // reducer: float4 pieces of the tile, all slabs of a piece loaded back to back (independent loads), summed in split
+        // order, then bias / SiLU / residual / x2 upsample and the store -- the whole epilogue of the inference form
+        constexpr int PCS = BN / 4;
+        const int S = g.sk_splits;
+        for (int pc = t; pc < BM * PCS; pc += 256) {
+            const int rl = pc / PCS, n = n0 + 4 * (pc - rl * PCS);
+            const int m = m0 + rl;
+            if (m >= g.M || n >= g.N) continue;
+            const float *src = g.sk_ws + (size_t)m * g.sk_ldws + n;
+            const size_t sstride = (size_t)g.M * g.sk_ldws;
+            f32x4 v = *(const f32x4 *)src;
+            int sp = 1;
+            for (; sp + 3 < S; sp += 4) {
+                f32x4 a0 = *(const f32x4 *)(src + sp * sstride), a1 = *(const f32x4 *)(src + (sp + 1) * sstride);
+                f32x4 a2 = *(const f32x4 *)(src + (sp + 2) * sstride), a3 = *(const f32x4 *)(src + (sp + 3) * sstride);
+                v += a0; v += a1; v += a2; v += a3;
+            }
+            for (; sp < S; ++sp) v += *(const f32x4 *)(src + sp * sstride);
+            size_t opix = (size_t)m;
+            if (g.up2) {
+                int q = fast_div(m, g.xo_magic, g.xo_shift), x = m - q * g.Xo;
+                int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
+                opix = ((size_t)b * (2 * g.Ho_f) + 2 * y) * (2 * g.Wo_f) + 2 * x;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= g.N) break;
+                float o = v[e] + (g.bias ? g.bias[n + e] : 0.f);
+                if (g.act) o = o * yh_sigmoid(o);
+                if (g.res) o += g.res[(size_t)m * g.ldr + n + e];
+                float *dst = g.out + opix * g.ldo + n + e;
+                dst[0] = o;
+                if (g.up2) {
+                    const size_t rs = (size_t)(2 * g.Wo_f) * g.ldo;
+                    dst[g.ldo] = o; dst[rs] = o; dst[rs + g.ldo] = o;
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: bias, optional accumulate, store, optional BatchNorm partial sums ----------
@@ -322,10 +406,10 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
     shift = l - 1;
 }
 
-template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT>
+template <int BM, int BN, int WM, int WN, int VEC, int NCLS, int MT, int SK = 0>
 int launch_cfg(GatherGemmSet gs, hipStream_t st) {
-    constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 27 * sizeof(int);
-    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC, NCLS, MT>;
+    constexpr size_t smem = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 28 * sizeof(int);
+    auto kern = gather_gemm_kernel<BM, BN, WM, WN, VEC, NCLS, MT, SK>;
     if (int rc = yh_ensure_dyn_smem((const void *)kern, smem)) return rc;
     int maxblk = 0;
     for (int c = 0; c < NCLS; ++c) {
@@ -335,7 +419,7 @@ int launch_cfg(GatherGemmSet gs, hipStream_t st) {
         int blk = cdiv(g.M, BM) * g.nblk_n;
         if (blk > maxblk) maxblk = blk;
     }
-    hipLaunchKernelGGL(kern, dim3(maxblk, NCLS), dim3(256), smem, st, gs);
+    hipLaunchKernelGGL(kern, dim3(maxblk, SK ? gs.c[0].sk_splits : NCLS), dim3(256), smem, st, gs);
     YH_CHECK_LAUNCH("gather_gemm");
     return 0;
 }
@@ -451,100 +535,80 @@ extern "C" int yh_conv_fwd_fused(const float *x, int ldx, const float *wf, int l
     return launch(g, (hipStream_t)stream);
 }
 
-// ---- small-M inference: split the 3x3 reduction over taps ---------------------------------------------------------
-// At batch 1 a 3x3 layer has few output tiles (7 x 4 workgroups for 256 -> 256 at 20x20) and a long K loop (72 chunks):
-// the layer's latency is one workgroup's K loop.  The taps are dealt to up to four "classes" of the multi-class launch
-// (the mechanism of the stride-2 backward-data), each writing its partial sums to a workspace slab; a small finish
-// kernel adds the slabs in fixed order and applies bias / SiLU / residual / x2 upsample.
+// ---- small-M inference: split-K inside one launch ------------------------------------------------------------------------
+// At batch 1 a layer has few output tiles (7 x 4 workgroups for 256 -> 256 at 20x20) and a long K loop (72 chunks): the
+// layer's latency is one workgroup's K loop on a mostly idle chip.  The K axis (taps x channels) is cut into S contiguous
+// chunk ranges, one workgroup per (tile, range); partial tiles go to fp32 slabs and the last workgroup to arrive at a tile
+// (an agent-scope ticket) adds them in range order and applies bias / SiLU / residual / x2 upsample -- no second launch,
+// bitwise reproducible.  ws layout: [S][M][ldws] floats, then one int32 ticket per tile (zero between launches).
 namespace {
-__global__ void splitk_finish_kernel(const float *__restrict__ ws, int ncls, int64_t M, int N, int ldws, const float *__restrict__ bias,
-                                     const float *__restrict__ res, int ldr, float *__restrict__ out, int ldo, int act, int up2,
-                                     int Ho, int Wo) {
-    const int nq = ldws >> 2;
-    const int64_t total = M * nq;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / nq;
-        const int n = (int)(i - m * nq) << 2;
-        f32x4 v = *(const f32x4 *)(ws + m * ldws + n);
-        for (int c = 1; c < ncls; ++c) v += *(const f32x4 *)(ws + ((int64_t)c * M + m) * ldws + n);
-        int64_t opix = m;
-        if (up2) {
-            int64_t q = m / Wo;
-            int x = (int)(m - q * Wo);
-            int64_t b = q / Ho;
-            int y = (int)(q - b * Ho);
-            opix = (b * (2 * Ho) + 2 * y) * (int64_t)(2 * Wo) + 2 * x;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (n + e >= N) break;
-            float t = v[e] + (bias ? bias[n + e] : 0.f);
-            if (act) t = t * yh_sigmoid(t);
-            if (res) t += res[m * ldr + n + e];
-            float *o = out + opix * ldo + n + e;
-            o[0] = t;
-            if (up2) {
-                const int64_t rs = (int64_t)(2 * Wo) * ldo;
-                o[ldo] = t; o[rs] = t; o[rs + ldo] = t;
-            }
-        }
-    }
-}
-
-int splitk_classes(int B, int Hi, int Wi, int Cout, int k, int s) {
-    if (k != 3) return 1;
-    const int Ho = (Hi + 2 - 3) / s + 1, Wo = (Wi + 2 - 3) / s + 1;
+struct SkPlan {
+    int bm, bn, tiles, splits, ldws;
+};
+SkPlan sk_plan(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
+    SkPlan p{};
+    const int pad = k / 2, Ho = (Hi + 2 * pad - k) / s + 1, Wo = (Wi + 2 * pad - k) / s + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
-    const int64_t tiles = ((M + 63) / 64) * ((Cout + 63) / 64);     // roughly the workgroups of the unsplit launch
-    return tiles < 256 ? 4 : 1;
+    p.bn = Cout <= 16 ? 16 : (Cout <= 32 ? 32 : 64);
+    p.bm = p.bn == 64 ? 64 : 128;
+    p.tiles = (int)(((M + p.bm - 1) / p.bm) * ((Cout + p.bn - 1) / p.bn));
+    p.ldws = (Cout + 3) / 4 * 4;
+    const int nch = (k * k * Cin + BK - 1) / BK;
+    static const int target = getenv("YH_SPLITK_TARGET") ? atoi(getenv("YH_SPLITK_TARGET")) : 192;    // workgroups per layer
+    int S = target / p.tiles;
+    if (S > nch / 2) S = nch / 2;          // at least two K chunks per split
+    if (S > 32) S = 32;
+    p.splits = (M > 65536 || S < 2) ? 1 : S;
+    return p;
 }
 }  // namespace
 
 extern "C" int64_t yh_conv_fwd_fused_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
-    (void)Cin;
-    const int nc = splitk_classes(B, Hi, Wi, Cout, k, s);
-    if (nc == 1) return 0;
-    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
-    return (int64_t)nc * B * Ho * Wo * ((Cout + 3) / 4 * 4);
+    const SkPlan p = sk_plan(B, Hi, Wi, Cin, Cout, k, s);
+    if (p.splits == 1) return 0;
+    const int pad = k / 2, Ho = (Hi + 2 * pad - k) / s + 1, Wo = (Wi + 2 * pad - k) / s + 1;
+    return (int64_t)p.splits * B * Ho * Wo * p.ldws + p.tiles;      // slabs + tickets (int32, one float slot each)
 }
 
 extern "C" int yh_conv_fwd_fused_splitk(const float *x, int ldx, const float *wf, int ldwf, const float *bias, const float *res,
                                         int ldr, float *y, int ldy, float *ws, int64_t ws_floats, int B, int Hi, int Wi, int Cin,
                                         int Cout, int k, int s, int act_silu, int upsample, void *stream) {
-    const int nc = splitk_classes(B, Hi, Wi, Cout, k, s);
-    if (nc == 1 || !ws) return yh_conv_fwd_fused(x, ldx, wf, ldwf, bias, res, ldr, y, ldy, B, Hi, Wi, Cin, Cout, k, s, act_silu, upsample, stream);
+    const SkPlan p = sk_plan(B, Hi, Wi, Cin, Cout, k, s);
+    const bool vec = (Cin % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    if (p.splits == 1 || !ws || !vec)
+        return yh_conv_fwd_fused(x, ldx, wf, ldwf, bias, res, ldr, y, ldy, B, Hi, Wi, Cin, Cout, k, s, act_silu, upsample, stream);
+    YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_fwd_fused_splitk: unsupported k=%d s=%d", k, s);
     YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_fwd_fused_splitk: bad argument");
     YH_REQUIRE(ldx >= Cin && ldy >= Cout && (!res || ldr >= Cout), "conv_fwd_fused_splitk: ld smaller than channel count");
     YH_REQUIRE(ws_floats >= yh_conv_fwd_fused_ws(B, Hi, Wi, Cin, Cout, k, s), "conv_fwd_fused_splitk: workspace too small");
-    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1, ldws = (Cout + 3) / 4 * 4;
+    const int pad = k / 2, Ho = (Hi + 2 * pad - k) / s + 1, Wo = (Wi + 2 * pad - k) / s + 1;
     const int64_t M = (int64_t)B * Ho * Wo;
-    static const int first[5] = {0, 3, 5, 7, 9};       // taps {0,1,2} {3,4} {5,6} {7,8}
-    GatherGemmSet gs{};
-    for (int c = 0; c < nc; ++c) {
-        GatherGemm g{};
-        g.in = x; g.w = wf; g.bias = nullptr; g.out = ws + (size_t)c * M * ldws; g.stats = nullptr;
-        g.Hi = Hi; g.Wi = Wi; g.ldi = ldx; g.Cin = Cin; g.ldw = ldwf;
-        g.Ho_f = Ho; g.Wo_f = Wo; g.ldo = ldws; g.N = Cout;
-        g.B = B; g.Yo = Ho; g.Xo = Wo; g.M = (int)M;
-        g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
-        g.accumulate = 0; g.dense = 1;
-        int nt = 0;
-        for (int t = first[c]; t < first[c + 1]; ++t) {
-            g.tap_dy[nt] = t / 3 - p; g.tap_dx[nt] = t % 3 - p; g.tap_w[nt] = t;
-            ++nt;
+    GatherGemm g{};
+    g.in = x; g.w = wf; g.bias = bias; g.out = y; g.stats = nullptr;
+    g.Hi = Hi; g.Wi = Wi; g.ldi = ldx; g.Cin = Cin; g.ldw = ldwf;
+    g.Ho_f = Ho; g.Wo_f = Wo; g.ldo = ldy; g.N = Cout;
+    g.B = B; g.Yo = Ho; g.Xo = Wo; g.M = (int)M;
+    g.osy = g.osx = 1; g.ooy = g.oox = 0; g.sy = g.sx = s;
+    g.nTaps = k * k; g.Ktot = g.nTaps * Cin; g.accumulate = 0; g.dense = 1;
+    g.res = res; g.ldr = ldr; g.act = act_silu ? 1 : 0; g.up2 = upsample ? 1 : 0;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            int t = kh * k + kw;
+            g.tap_dy[t] = kh - pad; g.tap_dx[t] = kw - pad; g.tap_w[t] = t;
         }
-        g.nTaps = nt; g.Ktot = nt * Cin;
-        gs.c[c] = g;
-    }
+    g.sk_splits = p.splits; g.sk_ldws = p.ldws; g.sk_ws = ws;
+    g.sk_cnt = (int *)(ws + (size_t)p.splits * M * p.ldws);
+    YH_REQUIRE(ldwf % 4 == 0 && ldwf >= Cout && ((uintptr_t)wf & 15) == 0, "conv_fwd_fused_splitk: weight pack misaligned");
+    YH_REQUIRE(g.Ktot < 65536 && (int64_t)B * Hi * Wi * ldx < (1ll << 31) && (int64_t)g.Ktot * ldwf < (1ll << 31),
+               "conv_fwd_fused_splitk: problem exceeds the 32-bit element-offset range");
+    set_magic((unsigned)g.Xo, g.xo_magic, g.xo_shift);
+    set_magic((unsigned)g.Yo, g.yo_magic, g.yo_shift);
+    GatherGemmSet gs{};
+    gs.c[0] = g;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_set<4>(gs, st);
-    if (rc) return rc;
-    const int64_t total = M * (ldws / 4);
-    int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, st, ws, nc, M, Cout, ldws, bias, res, ldr, y,
-                       ldy, act_silu ? 1 : 0, upsample ? 1 : 0, Ho, Wo);
-    YH_CHECK_LAUNCH("splitk_finish");
-    return 0;
+    if (p.bn == 16) return launch_cfg<128, 16, 4, 1, 4, 1, 16, 1>(gs, st);
+    if (p.bn == 32) return launch_cfg<128, 32, 4, 1, 4, 1, 32, 1>(gs, st);
+    return launch_cfg<64, 64, 2, 2, 4, 1, 32, 1>(gs, st);
 }
 
 extern "C" int yh_conv_bwd_data(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B,

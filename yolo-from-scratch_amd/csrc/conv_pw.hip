@@ -242,6 +242,8 @@ struct PwG {
     unsigned in_bytes, in2_bytes;
     const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns (common.h)
     int bn_n;
+    const float *res;           // inference epilogue (tiled kernel only): SiLU on (acc + bias), + residual, x2 upsample on write
+    int ldr, act, up2, H, W;    // H, W: image size (up2 needs the pixel's row / column)
 };
 
 template <int TM, int NT>
@@ -340,6 +342,17 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
                     float *o = ob + (size_t)p * ldo;
                     float v = acc[i][j][r] + bias;
                     if (g.accumulate) v += *o;
+                    if (g.act | g.up2 | (g.res != nullptr)) {      // inference form (uniform branch)
+                        if (g.act) v = v * yh_sigmoid(v);
+                        if (g.res) v += g.res[(size_t)p * g.ldr + n];
+                        if (g.up2) {
+                            const int q = p / g.W, x = p - q * g.W, b = q / g.H, y = q - b * g.H;
+                            float *u = ob + (((size_t)b * 2 * g.H + 2 * y) * 2 * g.W + 2 * x) * ldo;
+                            const size_t rs = (size_t)(2 * g.W) * ldo;
+                            u[0] = v; u[ldo] = v; u[rs] = v; u[rs + ldo] = v;
+                            continue;
+                        }
+                    }
                     *o = v;
                     if (ey) {
                         yh_bn_bwd_accum(v, ey[(size_t)p * eldy], esc, esh, emu, eis, s, q);
@@ -554,7 +567,8 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
     g.in_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + g.K1) * 4);
     g.in2_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + (g.K - g.K1)) * 4);
     const int NT = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
-    if (pw_use_stream(g.M, g.K, g.N)) {
+    const bool fused = g.act || g.up2 || g.res;          // the streaming form has no inference epilogue
+    if (!fused && pw_use_stream(g.M, g.K, g.N)) {
         dim3 sg(pw_stream_blocks(g.M));
         const int KC = g.K / 8;
 #define YH_PWS(nt, kc) hipLaunchKernelGGL((pw_stream_kernel<nt, kc>), sg, dim3(256), 0, st, g)
@@ -600,6 +614,17 @@ extern "C" int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw,
     PwG g{};
     g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
+    return launch_pw_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_pw_fwd_fused(const float *x, int ldx, const float *wq, int ldw, const float *bias, const float *res, int ldr,
+                                    float *y, int ldy, int B, int H, int W, int Cin, int Cout, int act_silu, int upsample, void *stream) {
+    const int64_t M = (int64_t)B * H * W;
+    YH_REQUIRE(x && wq && y && M > 0 && M < (1ll << 30) && ldx >= Cin && ldy >= Cout && (!res || ldr >= Cout), "conv_pw_fwd_fused: bad argument");
+    PwG g{};
+    g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = nullptr;
+    g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
+    g.res = res; g.ldr = ldr; g.act = act_silu ? 1 : 0; g.up2 = upsample ? 1 : 0; g.H = H; g.W = W;
     return launch_pw_gemm(g, (hipStream_t)stream);
 }
 

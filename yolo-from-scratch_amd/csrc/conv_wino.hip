@@ -36,6 +36,8 @@ struct Wino {
     int accumulate;
     const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns
     int bn_n;
+    const float *res;           // inference epilogue (eval-mode BatchNorm folded into U / bias): + residual after the activation,
+    int ldr, act, up2;          // act: SiLU on (acc + bias); up2: each output pixel replicated 2x2 (out is (B,2H,2W))
     unsigned tw_magic, tpi_magic;
     int tw_shift, tpi_shift;
 };
@@ -209,6 +211,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             float y1 = s[1][j] - s[2][j] - s[3][j] + bias;
             float *o0 = o + (size_t)j * g.ldo, *o1 = o0 + (size_t)g.W * g.ldo;
             if (g.accumulate) { y0 += *o0; y1 += *o1; }
+            if (g.act | g.up2 | (g.res != nullptr)) {          // inference form (uniform branch)
+                if (g.act) { y0 = y0 * yh_sigmoid(y0); y1 = y1 * yh_sigmoid(y1); }
+                const size_t p0 = (size_t)(b * g.H + 2 * ty) * g.W + 2 * tx + j;
+                if (g.res) { y0 += g.res[p0 * g.ldr + n]; y1 += g.res[(p0 + g.W) * g.ldr + n]; }
+                if (g.up2) {
+                    const size_t rs = (size_t)(2 * g.W) * g.ldo;
+                    float *u0 = g.out + (((size_t)b * 2 * g.H + 4 * ty) * 2 * g.W + 4 * tx + 2 * j) * g.ldo + n;
+                    float *u1 = u0 + 2 * rs;
+                    u0[0] = y0; u0[g.ldo] = y0; u0[rs] = y0; u0[rs + g.ldo] = y0;
+                    u1[0] = y1; u1[g.ldo] = y1; u1[rs] = y1; u1[rs + g.ldo] = y1;
+                    continue;
+                }
+            }
             *o0 = y0; *o1 = y1;
             if (ey) {
                 const size_t p0 = ((size_t)(b * g.H + 2 * ty) * g.W + 2 * tx + j) * eldy, p1 = p0 + (size_t)g.W * eldy;
@@ -628,6 +643,17 @@ extern "C" int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu
     Wino g{};
     g.in = x; g.U = U; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.ldi = ldx; g.ldu = ldu; g.ldo = ldy; g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = Cout; g.accumulate = 0;
+    return launch_wino(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_wino_fwd_fused(const float *x, int ldx, const float *U, int ldu, const float *bias, const float *res, int ldr,
+                                      float *y, int ldy, int B, int H, int W, int Cin, int Cout, int act_silu, int upsample,
+                                      void *stream) {
+    YH_REQUIRE(x && U && y && B > 0 && H > 0 && W > 0 && ldx >= Cin && ldy >= Cout && (!res || ldr >= Cout), "conv_wino_fwd_fused: bad argument");
+    Wino g{};
+    g.in = x; g.U = U; g.bias = bias; g.out = y; g.stats = nullptr;
+    g.ldi = ldx; g.ldu = ldu; g.ldo = ldy; g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = Cout; g.accumulate = 0;
+    g.res = res; g.ldr = ldr; g.act = act_silu ? 1 : 0; g.up2 = upsample ? 1 : 0;
     return launch_wino(g, (hipStream_t)stream);
 }
 

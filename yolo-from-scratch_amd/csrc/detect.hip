@@ -6,13 +6,13 @@
 // one IEEE rounding per operation, exactly as torchvision's CPU kernel does.
 //
 // Pipeline (all sizes are device-side: M is read from count[0], launches are sized by `cap`):
-//   1. keys = (descending-orderable score, candidate index) -> bitonic sort by one workgroup
-//      (LDS when the padded size fits 16384 keys, else in the workspace); ties in score keep the
-//      lower candidate index first = a stable descending sort.
-//   2. gather boxes/classes into sorted order.
-//   3. 64x64-tiled suppression bit matrix (upper triangle): bit (i, j) = j > i, same class, IoU > thr.
-//   4. one workgroup resolves the greedy scan: per 64-box block one wave walks the diagonal word in
-//      registers, then every thread ORs the kept rows into the removal word it owns.
+//   1. keys = (descending-orderable score, candidate index), all distinct -> position in the sorted order = number of
+//      smaller keys (rank counting, one thread per candidate over LDS-staged key tiles, whole chip); ties in score keep
+//      the lower candidate index first = a stable descending sort.  Boxes / classes are scattered to sorted order.
+//   2. 64x64-tiled suppression bit matrix (upper triangle): bit (i, j) = j > i, same class, IoU > thr; a fixed grid
+//      walks the blocks the device-side M needs.
+//   3. one workgroup resolves the greedy scan: per 64-box block one wave walks the (prefetched) diagonal word, then all
+//      threads OR the kept rows into the later removal words held in LDS (one (row, word) pair per thread).
 #pragma clang fp contract(off)
 #include "common.h"
 
@@ -108,8 +108,9 @@ __global__ void cand_write_kernel(const CandArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int kSortLds = 16384;   // keys that fit the 128 KiB LDS sort buffer
 constexpr int kNmsThreads = 1024;
+constexpr int kRankTile = 1024;   // keys staged in LDS per pass of the rank kernel
+constexpr int kMaxWords = 4096;   // mask words per row the scan keeps in LDS (cap <= 64 * kMaxWords)
 
 __device__ __forceinline__ uint64_t make_key(float score, int idx) {
     uint32_t u = __float_as_uint(score);
@@ -117,137 +118,147 @@ __device__ __forceinline__ uint64_t make_key(float score, int idx) {
     return ((uint64_t)(~u) << 32) | (uint32_t)idx;    // ascending key = descending score, then index
 }
 
-__device__ void bitonic_sort(uint64_t *k, int n) {   // n is a power of two; whole workgroup
-    for (int size = 2; size <= n; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
-                int lo = 2 * i - (i & (stride - 1));
-                int hi = lo + stride;
-                bool up = (lo & size) == 0;
-                uint64_t a = k[lo], b = k[hi];
-                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
-            }
-        }
-    __syncthreads();
-}
-
 struct NmsArgs {
     const float *boxes, *scores;
     const int32_t *classes, *count;
     int cap, W;                 // W = words per mask row = ceil(cap/64)
     float thr;
-    uint64_t *keys;             // [pow2(cap)]
     float *sboxes;              // [cap][4]
     int32_t *sclasses, *order;  // [cap]
     uint64_t *mask;             // [cap][W]
     int32_t *keep, *nkeep;
 };
 
-__global__ __launch_bounds__(kNmsThreads) void nms_sort_kernel(const NmsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lkeys[];
+// Stable descending-score order by RANK COUNTING: the keys (score, candidate index) are unique, so the position of a
+// candidate in the sorted order is the number of keys smaller than its own.  One thread per candidate walks all M keys
+// (staged through LDS, broadcast reads) -- M^2 / 2^8 compares per workgroup spread over the whole chip, ~10 us at
+// M = 3000 where a single-workgroup LDS bitonic sort took 75 us of barriers.
+__global__ __launch_bounds__(256) void nms_rank_kernel(const NmsArgs a) {
+    __shared__ uint64_t tile[kRankTile];
     int M = a.count[0];
     if (M > a.cap) M = a.cap;
-    int n = 1;
-    while (n < M) n <<= 1;
-    uint64_t *k = n <= kSortLds ? lkeys : a.keys;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) k[i] = i < M ? make_key(a.scores[i], i) : ~0ull;
-    if (n > 1) bitonic_sort(k, n);
-    __syncthreads();
-    for (int r = threadIdx.x; r < M; r += blockDim.x) {
-        int idx = (int)(uint32_t)k[r];
-        a.order[r] = idx;
-        a.sclasses[r] = a.classes[idx];
-        *(f32x4 *)(a.sboxes + 4 * r) = *(const f32x4 *)(a.boxes + 4 * idx);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= M) return;              // whole workgroup out of range (uniform)
+    const uint64_t mine = i < M ? make_key(a.scores[i], i) : ~0ull;
+    int rank = 0;
+    for (int base = 0; base < M; base += kRankTile) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < kRankTile; j += 256) {
+            int c = base + j;
+            tile[j] = c < M ? make_key(a.scores[c], c) : ~0ull;       // padding keys are never smaller than a real key
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < kRankTile; ++j) rank += tile[j] < mine ? 1 : 0;
+    }
+    if (i < M) {
+        a.order[rank] = i;
+        a.sclasses[rank] = a.classes[i];
+        *(f32x4 *)(a.sboxes + 4 * rank) = *(const f32x4 *)(a.boxes + 4 * i);
     }
 }
 
-__global__ void nms_mask_kernel(const NmsArgs a) {
+// 64 x 64 blocks of the suppression bit matrix, upper triangle only (row block <= column block); a fixed grid of
+// workgroups walks the blocks the actual candidate count needs (M lives on the device).
+__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
     int M = a.count[0];
     if (M > a.cap) M = a.cap;
-    const int rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb || rb * 64 >= M || cb * 64 >= M) return;
+    const int nw = (M + 63) >> 6;
+    const int npairs = nw * (nw + 1) / 2;
     __shared__ float cbx[64][4];
     __shared__ int ccl[64];
-    const int t = threadIdx.x, cj = cb * 64 + t;
-    if (cj < M) {
-        *(f32x4 *)cbx[t] = *(const f32x4 *)(a.sboxes + 4 * cj);
-        ccl[t] = a.sclasses[cj];
+    const int t = threadIdx.x;
+    for (int p = blockIdx.x; p < npairs; p += gridDim.x) {
+        // p -> (rb, cb), rb <= cb: row rb starts at rb * nw - rb (rb - 1) / 2
+        int rb = (int)(((2.0f * nw + 1.0f) - sqrtf((2.0f * nw + 1.0f) * (2.0f * nw + 1.0f) - 8.0f * (float)p)) * 0.5f);
+        if (rb < 0) rb = 0;
+        if (rb > nw - 1) rb = nw - 1;
+        while (rb > 0 && rb * nw - rb * (rb - 1) / 2 > p) --rb;
+        while ((rb + 1) * nw - (rb + 1) * rb / 2 <= p) ++rb;
+        const int cb = rb + (p - (rb * nw - rb * (rb - 1) / 2));
+        const int cj = cb * 64 + t;
+        __syncthreads();
+        if (cj < M) {
+            *(f32x4 *)cbx[t] = *(const f32x4 *)(a.sboxes + 4 * cj);
+            ccl[t] = a.sclasses[cj];
+        }
+        __syncthreads();
+        const int i = rb * 64 + t;
+        if (i >= M) continue;
+        f32x4 bi = *(const f32x4 *)(a.sboxes + 4 * i);
+        const int ci = a.sclasses[i];
+        const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+        uint64_t bits = 0;
+        int ncol = M - cb * 64;
+        if (ncol > 64) ncol = 64;
+        for (int c = (rb == cb ? t + 1 : 0); c < ncol; ++c) {
+            if (ccl[c] != ci) continue;
+            float xx1 = fmaxf(bi[0], cbx[c][0]), yy1 = fmaxf(bi[1], cbx[c][1]);
+            float xx2 = fminf(bi[2], cbx[c][2]), yy2 = fminf(bi[3], cbx[c][3]);
+            float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+            float inter = w * h;
+            float aj = (cbx[c][2] - cbx[c][0]) * (cbx[c][3] - cbx[c][1]);
+            float iou = inter / ((ai + aj) - inter);
+            if (iou > a.thr) bits |= 1ull << c;
+        }
+        a.mask[(size_t)i * a.W + cb] = bits;
     }
-    __syncthreads();
-    const int i = rb * 64 + t;
-    if (i >= M) return;
-    f32x4 bi = *(const f32x4 *)(a.sboxes + 4 * i);
-    const int ci = a.sclasses[i];
-    const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
-    uint64_t bits = 0;
-    int ncol = M - cb * 64;
-    if (ncol > 64) ncol = 64;
-    for (int c = (rb == cb ? t + 1 : 0); c < ncol; ++c) {
-        if (ccl[c] != ci) continue;
-        float xx1 = fmaxf(bi[0], cbx[c][0]), yy1 = fmaxf(bi[1], cbx[c][1]);
-        float xx2 = fminf(bi[2], cbx[c][2]), yy2 = fminf(bi[3], cbx[c][3]);
-        float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-        float inter = w * h;
-        float aj = (cbx[c][2] - cbx[c][0]) * (cbx[c][3] - cbx[c][1]);
-        float iou = inter / ((ai + aj) - inter);
-        if (iou > a.thr) bits |= 1ull << c;
-    }
-    a.mask[(size_t)i * a.W + cb] = bits;
 }
 
+// Greedy scan in descending score order, 64 candidates per step.  The removal words live in LDS.  Per step: wave 0
+// resolves the block against its own (prefetched) diagonal word with a scalar chain, then ALL threads OR the mask rows
+// of the newly kept candidates into the later removal words -- one (kept row, word) pair per thread, LDS atomic OR (order
+// independent, so the result is deterministic); the serial part of a step is the 64-long chain only.
 __global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) {
-    __shared__ uint64_t cur_word, kept_word;
-    __shared__ int nk_sh;
+    __shared__ uint64_t remv[kMaxWords];
+    __shared__ int klist[64];
+    __shared__ int nkept_sh, nk_sh;
     int M = a.count[0];
     if (M > a.cap) M = a.cap;
     const int nw = (M + 63) >> 6;
     const int t = threadIdx.x, lane = t & 63;
-    // each thread owns removal words t, t+1024, ... (at most cap/64/1024 of them: keep 4)
-    uint64_t remv[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int w = t + q * kNmsThreads;
-        if (w == nw - 1 && (M & 63)) remv[q] = ~0ull << (M & 63);   // boxes past M never win
-    }
+    for (int w = t; w < nw; w += kNmsThreads) remv[w] = (w == nw - 1 && (M & 63)) ? ~0ull << (M & 63) : 0ull;   // boxes past M never win
     if (t == 0) nk_sh = 0;
+    uint64_t diag_next = 0;
+    if (t < 64 && nw > 0) diag_next = lane < M ? a.mask[(size_t)lane * a.W] : 0ull;
     __syncthreads();
     for (int bi = 0; bi < nw; ++bi) {
-        const int owner = bi % kNmsThreads, slot = bi / kNmsThreads;
-        if (t == owner) {
-            uint64_t v = slot == 0 ? remv[0] : (slot == 1 ? remv[1] : (slot == 2 ? remv[2] : remv[3]));
-            cur_word = v;
-        }
-        __syncthreads();
-        if (t < 64) {   // wave 0 resolves the block against its own diagonal word
-            const int row = bi * 64 + lane;
-            uint64_t diag = row < M ? a.mask[(size_t)row * a.W + bi] : 0ull;
-            uint64_t cur = cur_word, kept = 0;
+        if (t < 64) {
+            const uint64_t diag = diag_next;
+            if (bi + 1 < nw) {                     // the next block's diagonal word does not depend on this block's outcome
+                const int r = (bi + 1) * 64 + lane;
+                diag_next = r < M ? a.mask[(size_t)r * a.W + bi + 1] : 0ull;
+            }
+            uint64_t cur = remv[bi], kept = 0;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+#pragma unroll
             for (int b = 0; b < 64; ++b) {
-                uint64_t d = __shfl(diag, b);
+                const uint64_t d = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
                 if (!((cur >> b) & 1ull)) { kept |= 1ull << b; cur |= d; }
             }
-            int base = nk_sh;
-            if ((kept >> lane) & 1ull) a.keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = a.order[row];
-            if (lane == 0) { kept_word = kept; nk_sh = base + __popcll(kept); }
+            const int base = nk_sh;
+            if ((kept >> lane) & 1ull) {
+                const int pos = __popcll(kept & ((1ull << lane) - 1ull));
+                a.keep[base + pos] = a.order[bi * 64 + lane];
+                klist[pos] = lane;
+            }
+            if (lane == 0) { nkept_sh = __popcll(kept); nk_sh = base + __popcll(kept); }
         }
         __syncthreads();
-        const uint64_t kept = kept_word;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int w = t + q * kNmsThreads;
-            if (w > bi && w < nw) {
-                uint64_t acc = remv[q], kk = kept;
-                while (kk) {
-                    int b = __ffsll((long long)kk) - 1;
-                    kk &= kk - 1;
-                    acc |= a.mask[(size_t)(bi * 64 + b) * a.W + w];
-                }
-                remv[q] = acc;
+        const int nkept = nkept_sh, nrem = nw - bi - 1;
+        const int total = nkept * nrem;
+        for (int idx = t; idx < total; idx += kNmsThreads) {
+            const int kb = idx / nrem, w = bi + 1 + (idx - kb * nrem);
+            const uint64_t v = a.mask[(size_t)(bi * 64 + klist[kb]) * a.W + w];
+            if (v) {
+                unsigned *r32 = (unsigned *)&remv[w];
+                if ((unsigned)v) atomicOr(r32, (unsigned)v);
+                if ((unsigned)(v >> 32)) atomicOr(r32 + 1, (unsigned)(v >> 32));
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (t == 0) a.nkeep[0] = nk_sh;
 }
 
@@ -349,8 +360,7 @@ extern "C" int yh_candidates(const float *const pred[3], const float *anchors, c
 extern "C" int64_t yh_nms_ws(int cap) {
     if (cap <= 0) return 0;
     size_t W = (size_t)(cap + 63) / 64;
-    size_t b = align_up((size_t)pow2_ge(cap) * 8, 256);   // keys
-    b += align_up((size_t)cap * 16, 256);                 // sorted boxes
+    size_t b = align_up((size_t)cap * 16, 256);           // sorted boxes
     b += 2 * align_up((size_t)cap * 4, 256);              // sorted classes, order
     b += align_up((size_t)cap * W * 8, 256);              // suppression bit matrix
     return (int64_t)b;
@@ -359,24 +369,21 @@ extern "C" int64_t yh_nms_ws(int cap) {
 extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count, int cap,
                       float iou_thr, int32_t *keep, int32_t *nkeep, void *ws, void *stream) {
     YH_REQUIRE(boxes && scores && classes && count && keep && nkeep && ws && cap > 0, "nms: bad argument");
-    YH_REQUIRE(cap <= 64 * 4 * kNmsThreads, "nms: capacity %d above the supported %d", cap, 64 * 4 * kNmsThreads);
+    YH_REQUIRE(cap <= 64 * kMaxWords, "nms: capacity %d above the supported %d", cap, 64 * kMaxWords);
     YH_REQUIRE(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)ws & 255) == 0, "nms: boxes 16-byte / workspace 256-byte alignment");
     NmsArgs a{};
     a.boxes = boxes; a.scores = scores; a.classes = classes; a.count = count;
     a.cap = cap; a.W = (cap + 63) / 64; a.thr = iou_thr; a.keep = keep; a.nkeep = nkeep;
     char *p = (char *)ws;
-    a.keys = (uint64_t *)p;   p += align_up((size_t)pow2_ge(cap) * 8, 256);
     a.sboxes = (float *)p;    p += align_up((size_t)cap * 16, 256);
     a.sclasses = (int32_t *)p; p += align_up((size_t)cap * 4, 256);
     a.order = (int32_t *)p;   p += align_up((size_t)cap * 4, 256);
     a.mask = (uint64_t *)p;
     hipStream_t st = (hipStream_t)stream;
-    int n = pow2_ge(cap);
-    size_t lds = (size_t)(n < kSortLds ? n : kSortLds) * 8;
-    if (int rc = yh_ensure_dyn_smem((const void *)nms_sort_kernel, lds)) return rc;
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(kNmsThreads), lds, st, a);
-    YH_CHECK_LAUNCH("nms_sort");
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(a.W, a.W), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, st, a);
+    YH_CHECK_LAUNCH("nms_rank");
+    const int64_t pairs = (int64_t)a.W * (a.W + 1) / 2;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)(pairs < 2048 ? pairs : 2048)), dim3(64), 0, st, a);
     YH_CHECK_LAUNCH("nms_mask");
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kNmsThreads), 0, st, a);
     YH_CHECK_LAUNCH("nms_scan");

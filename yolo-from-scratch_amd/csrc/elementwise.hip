@@ -132,6 +132,34 @@ __global__ void pack_fold_multi_kernel(const FoldDesc *__restrict__ tab) {
         }
 }
 
+// Inference: eval-mode BatchNorm folded into OIHW weights (the input of every per-kernel weight transform) and a bias,
+//   w'[n][...] = w[n][...] * gamma[n] / sqrt(rv[n] + eps),   b'[n] = (b[n] - rm[n]) * that + beta[n];  gamma == NULL: copy.
+struct FoldOihwDesc {
+    const float *w, *bias_in, *gamma, *beta, *rmean, *rvar;
+    float *w_out, *bias_out;
+    int Cout, per;          // per = Cin * k * k elements per output channel
+    float eps;
+    int pad;
+};
+__global__ void fold_oihw_multi_kernel(const FoldOihwDesc *__restrict__ tab) {
+    const FoldOihwDesc d = tab[blockIdx.y];
+    const int total = d.Cout * d.per;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / d.per;
+        const float sc = d.gamma ? d.gamma[n] * (1.0f / sqrtf(d.rvar[n] + d.eps)) : 1.f;
+        d.w_out[i] = d.w[i] * sc;
+    }
+    if (blockIdx.x == 0 && d.bias_out)
+        for (int n = threadIdx.x; n < d.Cout; n += blockDim.x) {
+            float b = d.bias_in ? d.bias_in[n] : 0.f;
+            if (d.gamma) {
+                float sc = d.gamma[n] * (1.0f / sqrtf(d.rvar[n] + d.eps));
+                b = (b - d.rmean[n]) * sc + d.beta[n];
+            }
+            d.bias_out[n] = b;
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column sums: stage 1 -> partial[blk][C], stage 2 -> out[C]
 // vector path (C % 4 == 0, 16-byte addressable rows): float4 columns x row groups, like the BN reductions
@@ -590,6 +618,14 @@ extern "C" int yh_pack_fold_multi(const void *table, int n_layers, void *stream)
     hipLaunchKernelGGL(pack_fold_multi_kernel, dim3(32, n_layers), dim3(256), 0, (hipStream_t)stream,
                        (const FoldDesc *)table);
     YH_CHECK_LAUNCH("pack_fold_multi");
+    return 0;
+}
+
+extern "C" int yh_fold_oihw_multi(const void *table, int n_layers, void *stream) {
+    YH_REQUIRE(table && n_layers > 0, "fold_oihw_multi: bad argument");
+    static_assert(sizeof(FoldOihwDesc) == 80, "descriptor layout is part of the ABI");
+    hipLaunchKernelGGL(fold_oihw_multi_kernel, dim3(32, n_layers), dim3(256), 0, (hipStream_t)stream, (const FoldOihwDesc *)table);
+    YH_CHECK_LAUNCH("fold_oihw_multi");
     return 0;
 }
 

@@ -24,6 +24,8 @@ import torch
 from . import _lib as L
 
 BN_EPS_DEFAULT = 1e-5
+# bumped whenever this package's kernels modify parameters or BatchNorm buffers in place (see Plan.weights_state)
+WEIGHTS_EPOCH = [0]
 
 
 def _rup4(c: int) -> int:
@@ -159,6 +161,9 @@ class Plan:
         self.param_ptrs: List[int] = []
         self._sig_holders = None
         self._grad_of = None
+        self.prep_ops = None               # eval plans: BatchNorm folding, run once per weight state
+        self._fold_tensors = None
+        self._folded_state = None
 
     # ---- tracing API used by the modules ------------------------------------------------------
     def new_buffer(self, B, H, W, C, name="act", dtype=None, grad_C=None) -> Buffer:
@@ -296,24 +301,50 @@ class Plan:
                     r.ldwf = _rup4(r.cout)
                     r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
                 if not self.training:
-                    # eval: one fused kernel per conv -- conv + folded-BN bias + SiLU (+residual) (+x2 upsample)
-                    fbias = torch.empty(r.cout, **f32)
-                    keep.append(fbias)
+                    # eval: one fused kernel per conv -- conv + folded-BN bias + SiLU (+residual) (+x2 upsample).  BatchNorm
+                    # is folded into an OIHW copy of the weights (yh_fold_oihw_multi), which then goes through the weight
+                    # transform of whichever kernel family runs the layer: Winograd / pointwise GEMM for layers with enough
+                    # workgroups to fill the chip (eval_epoch, predict_batch), the gather-GEMM with in-launch split-K for
+                    # the small-M layers of batch-1 inference.
                     bn = r.bn
+                    cin_real = r.weight.shape[1]
+                    fbias = torch.empty(r.cout, **f32)
+                    wfold = torch.empty(r.cout * cin_real * kk, **f32)
+                    keep += [fbias, wfold]
                     folds.append((r.weight.data_ptr(), r.bias.data_ptr() if r.bias is not None else 0,
                                   bn.weight.data_ptr() if bn is not None else 0, bn.bias.data_ptr() if bn is not None else 0,
                                   bn.running_mean.data_ptr() if bn is not None else 0,
-                                  bn.running_var.data_ptr() if bn is not None else 0, r.wf.data_ptr(), fbias.data_ptr(),
-                                  r.cout, r.weight.shape[1], kk, r.cin, r.ldwf, float(bn.eps) if bn is not None else 0.0))
-                    nws = int(lib.yh_conv_fwd_fused_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s)) \
-                        if os.environ.get("YH_SPLITK", "1") != "0" else 0
-                    sws = torch.empty(nws, **f32) if nws > 0 else None      # per layer: two lanes may run split layers at once
-                    if sws is not None:
-                        keep.append(sws)
-                    fwd.append(_op(L.OP_CONV_FWD_FUSED,
-                                   p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr(), sws],
-                                   i=[r.x.ld, r.ldwf, r.residual.ld if r.residual else 0, r.out.ld, r.x.B, r.x.H, r.x.W,
-                                      r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], l=[nws], lane=ln))
+                                  bn.running_var.data_ptr() if bn is not None else 0, wfold.data_ptr(), fbias.data_ptr(),
+                                  r.cout, cin_real * kk, float(bn.eps) if bn is not None else 0.0, 0))
+                    fast = os.environ.get("YH_EVAL_FAST", "1") != "0"
+                    M = r.x.B * r.Ho * r.Wo
+                    aligned = r.cin == cin_real and r.x.ld % 4 == 0
+                    wino_e = fast and aligned and r.k == 3 and r.s == 1 and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.cin % 16 == 0 \
+                        and r.cin <= 2048 and ((M // 4 + 31) // 32) * ((r.cout + 63) // 64) >= 192
+                    pw_e = fast and aligned and r.k == 1 and r.s == 1 and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256) \
+                        and ((M + 127) // 128) * ((r.cout + 127) // 128) >= 128
+                    args = dict(i=[r.x.ld, r.ldwf, r.residual.ld if r.residual else 0, r.out.ld, r.x.B, r.x.H, r.x.W,
+                                   r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], lane=ln)
+                    if wino_e:
+                        r.wf = torch.empty(16 * r.cin * r.ldwf, **f32)
+                        winos.append((wfold.data_ptr(), r.wf.data_ptr(), r.cout, cin_real, r.ldwf, 0))
+                        fwd.append(_op(L.OP_CONV_WINO_FWD_FUSED,
+                                       p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()], **args))
+                    elif pw_e:
+                        r.wf = torch.zeros(r.cin * r.ldwf, **f32)
+                        pwpacks.append((wfold.data_ptr(), r.wf.data_ptr(), 0, r.cout, r.cin, r.ldwf, r.ldwb, 0, 0))
+                        fwd.append(_op(L.OP_CONV_PW_FWD_FUSED,
+                                       p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()], **args))
+                    else:
+                        packs.append((wfold.data_ptr(), r.wf.data_ptr(), 0, r.cout, cin_real, kk, r.cin, r.ldwf, r.ldwb))
+                        nws = int(lib.yh_conv_fwd_fused_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s)) \
+                            if os.environ.get("YH_SPLITK", "1") != "0" else 0
+                        sws = torch.zeros(nws, **f32) if nws > 0 else None   # per layer (two lanes may run split layers at once); zero tickets
+                        if sws is not None:
+                            keep.append(sws)
+                        fwd.append(_op(L.OP_CONV_FWD_FUSED,
+                                       p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr(), sws],
+                                       l=[nws], **args))
                     continue
                 r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
                 wino_ok = use_wino and r.k == 3 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.x.ld % 4 == 0
@@ -420,28 +451,30 @@ class Plan:
                 r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
                 fwd.append(_op(L.OP_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
                                i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C], lane=ln))
-        if folds:
-            import struct
-            blob = b"".join(struct.pack("<QQQQQQQQiiiiif", *d) for d in folds)
-            self.fold_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-            fwd.insert(0, _op(L.OP_PACK_FOLD_MULTI, p=[self.fold_table], i=[len(folds)]))
-        for o in s2m_packs:
-            fwd.insert(0, o)
+        import struct
+        head: List[L.YhOp] = list(reversed(s2m_packs))     # weight transforms: head of the forward list (training) / prep list (eval)
         if pwpacks:
-            import struct
             blob = b"".join(struct.pack("<QQQiiiiii", *d) for d in pwpacks)
             self.pw_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-            fwd.insert(0, _op(L.OP_PW_PACK_MULTI, p=[self.pw_table], i=[len(pwpacks)]))
+            head.insert(0, _op(L.OP_PW_PACK_MULTI, p=[self.pw_table], i=[len(pwpacks)]))
         if winos:
-            import struct
             blob = b"".join(struct.pack("<QQiiii", *d) for d in winos)
             self.wino_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-            fwd.insert(0, _op(L.OP_WINO_WEIGHTS_MULTI, p=[self.wino_table], i=[len(winos)]))
-        if packs:   # every conv's OIHW -> packed copies in ONE launch at the head of the forward list
-            import struct
+            head.insert(0, _op(L.OP_WINO_WEIGHTS_MULTI, p=[self.wino_table], i=[len(winos)]))
+        if packs:   # every conv's OIHW -> packed copies in ONE launch
             blob = b"".join(struct.pack("<QQQiiiiiiii", *d, 0, 0) for d in packs)
             self.pack_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-            fwd.insert(0, _op(L.OP_PACK_WEIGHTS_MULTI, p=[self.pack_table], i=[len(packs)]))
+            head.insert(0, _op(L.OP_PACK_WEIGHTS_MULTI, p=[self.pack_table], i=[len(packs)]))
+        if folds:
+            # eval: BatchNorm folding + the transforms of the folded weights read only parameters and running statistics:
+            # they run once per weight state (refresh_folded_weights), not once per forward -- at batch 1 the fold was the
+            # longest launch of the pass
+            blob = b"".join(struct.pack("<QQQQQQQQiifi", *d) for d in folds)
+            self.fold_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            head.insert(0, _op(L.OP_FOLD_OIHW_MULTI, p=[self.fold_table], i=[len(folds)]))
+            self.prep_ops = _pack(head)
+        else:
+            fwd = head + fwd
         self.fwd_ops = _pack(fwd)
         self.bwd_ops = _pack(self._lower_backward(grad_of, keep)) if self.training else None
         self._keep = keep
@@ -576,7 +609,10 @@ class Plan:
                 if r.out.off != 0 or r.out.ldg != kcout:
                     raise NotImplementedError("head gradient must own its (padded) buffer")
             if r.bias is not None:
-                ops.append(_op(L.OP_BF16_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
+                # head biases (18 / 255 channels): sum the zero-padded multiple of 4 so the vector kernel applies; the extra
+                # column sums are exact zeros and land in the 4-float padding every tensor has in the flat gradient buffer
+                cs = _rup4(r.cout) if (r.bn is None and _rup4(r.cout) <= lddy) else r.cout
+                ops.append(_op(L.OP_BF16_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, cs], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
             ops.append(_op(L.OP_BF16_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s], l=[self.ws.numel()]))
@@ -791,7 +827,37 @@ class Plan:
         dev = self.device.index
         return torch.cuda.device(dev) if dev is not None and torch.cuda.current_device() != dev else _NullCtx()
 
+    def weights_state(self):
+        """What the folded inference weights were computed from: the process-wide counter of in-place updates made by this
+        package's own kernels (which write through raw pointers and so bypass torch's version counters: optimizer steps,
+        BatchNorm running statistics of training forwards) plus torch's version counter of every tensor the fold reads."""
+        if self._fold_tensors is None:
+            self._signature()
+            self._fold_tensors = [(o, a) for o, a in self._sig_holders if a != "num_batches_tracked"]
+        v = 0
+        for o, a in self._fold_tensors:
+            t = getattr(o, a)
+            if t is not None:
+                v += t._version
+        return (WEIGHTS_EPOCH[0], v)
+
+    def refresh_folded_weights(self, stream: int) -> bool:
+        """Eval plans: (re)fold BatchNorm into the packed weights when the weights changed since the last fold."""
+        if self.prep_ops is None:
+            return False
+        state = self.weights_state()
+        if state == self._folded_state:
+            return False
+        with self._on_device():
+            L.run_ops(self.prep_ops[0], self.prep_ops[1], stream, None)
+        self._folded_state = state
+        return True
+
     def run_forward(self, stream: int):
+        if self.training:
+            WEIGHTS_EPOCH[0] += 1          # running statistics / num_batches_tracked are about to change under torch's radar
+        else:
+            self.refresh_folded_weights(stream)
         with self._on_device():
             L.run_ops(self.fwd_ops[0], self.fwd_ops[1], stream, self._ctx())
         self.generation += 1

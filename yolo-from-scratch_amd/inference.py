@@ -173,6 +173,7 @@ class InferenceSession:
         if self.det is None or self.det.grids != grids:
             self.det = Detector(grids, self.nc, self.device)
         self.graph = None
+        self.plan.refresh_folded_weights(_stream(self.device))
         if self.use_graph:
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -186,8 +187,10 @@ class InferenceSession:
                 self._enqueue()
 
     def _enqueue(self):
+        """Everything a replay repeats.  BatchNorm folding is NOT in here: it depends on the weights only and runs (eagerly,
+        before the replay) when Plan.refresh_folded_weights sees a new weight state."""
         self.model._load_input(self.plan, self.x)
-        self.plan.run_forward(_stream(self.device))
+        L.run_ops(self.plan.fwd_ops[0], self.plan.fwd_ops[1], _stream(self.device), self.plan._ctx())
         preds = [v.buf.data.view(1, v.H, v.W, 3, v.C // 3) for v in self.heads]
         self.det.candidates(preds, self.model.anchors, self.S, self.conf, letterbox_dev=self.lb)
         self.det.nms(self.iou)
@@ -196,6 +199,7 @@ class InferenceSession:
         """img: (1,3,S,S) or (3,S,S) float tensor (host or device).  Returns the detections list."""
         if self.plan.params_moved():
             self._build()
+        self.plan.refresh_folded_weights(_stream(self.device))
         self.x.copy_(img.reshape(self.x.shape), non_blocking=True)
         self.lb.copy_(torch.tensor([pad_left, pad_top, scale], dtype=torch.float32), non_blocking=True)
         if self.graph is not None:

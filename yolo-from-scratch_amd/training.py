@@ -16,6 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from .functional import LOSS_IMG_SIZE, _anchors18, run_loss_kernel, yolo_loss_multiscale
+from .graph import WEIGHTS_EPOCH
 from .hostside import stack_targets
 from .modules import HipModule
 
@@ -173,6 +174,7 @@ class HipTrainer:
         n = self.flat_g.numel()
         gscale = 1.0 / self.world
         self.step_count += 1
+        WEIGHTS_EPOCH[0] += 1               # the fused kernel rewrites the parameters in place (folded eval weights go stale)
         clip = self.max_norm is not None and self.max_norm > 0
         if clip:
             L.check(lib.yh_grad_sqnorm(self.flat_g.data_ptr(), n, gscale, self.norm.data_ptr(), self.norm_ws.data_ptr(), st),
