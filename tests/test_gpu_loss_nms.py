@@ -148,7 +148,14 @@ def test_candidates_and_nms_pipeline_vs_reference_capture(tag):
     got = det.keep[: int(det.nkeep.item())].cpu().numpy()
     want = orc.nms_batched(det.boxes[:M].cpu().numpy(), det.scores[:M].cpu().numpy(), det.classes[:M].cpu().numpy(), 0.4)
     np.testing.assert_array_equal(got, want)                  # bit-exact index selection on identical inputs
-    # NMS on the reference-captured candidates selects (nearly) the same set: fp32 ulps in box corners can
-    # flip pairs sitting on the IoU threshold, and one flip cascades, so only a loose overlap is asserted here
+    # The reference-captured candidates are the same cells with boxes / scores that differ by fp32 rounding (GPU expf vs
+    # torch-CPU sigmoid).  Every decision of the GPU's scan is replayed against the reference's values: it must agree
+    # unless the pair's IoU straddles the threshold between the two evaluations (tests/nms_explain.py); with no such pair
+    # the two selections must be identical.
+    from nms_explain import explain_selection
+    ambiguous, swaps = explain_selection(det.boxes[:M].cpu().numpy(), det.scores[:M].cpu().numpy(), g[f"{tag}/boxes"],
+                                         g[f"{tag}/scores"], g[f"{tag}/classes"], got, 0.4)
     ref_sel = orc.nms_batched(g[f"{tag}/boxes"], g[f"{tag}/scores"], g[f"{tag}/classes"], 0.4)
-    assert len(set(got.tolist()) & set(ref_sel.tolist())) >= 0.8 * len(ref_sel)
+    assert len(ambiguous) <= max(2, M // 200), ambiguous
+    if not ambiguous and not swaps:
+        np.testing.assert_array_equal(got, ref_sel)

@@ -140,8 +140,68 @@ def test_fused_trainer_step_matches_reference_golden(tag, nc, S):
             assert np.abs(dgot[strong] - dref[strong]).max() <= 2e-2 * np.abs(dref[strong]).max(), n
             checked += int(strong.sum())
     assert checked > 1000
+    # the second-step loss is compared loosely here (the golden holds only samples of the update); the precise statement --
+    # oracle loss + first-order effect of the implementation-dependent +-lr moves, to 2e-4 -- is
+    # test_second_step_loss_is_explained_to_first_order
     out2 = tr.step(xg, tg).cpu().numpy()
     close(out2[:4], g["scalars_step2"], 2e-3, 1e-5)
+
+
+@pytest.mark.parametrize("nc,S,B", [(1, 320, 2), (3, 320, 2)])
+def test_second_step_loss_is_explained_to_first_order(nc, S, B):
+    """Why post-update quantities cannot be compared at 1e-4 directly, and what CAN be: Adam's first step is
+    -lr * g / (|g| + eps) = -lr * sign(g), so an element whose gradient is smaller than the fp32 error of the gradient
+    itself moves by +-lr in an implementation-dependent direction (the seven Q2 conv biases in front of BatchNorm are the
+    extreme case: their true gradient is 0).  The claims tested here, against the CPU oracle on full tensors:
+      (1) only such noise-level elements move differently: every element whose first update differs from the oracle's by
+          more than 1 % of lr has |g| <= 2e-3 * max|g| of its tensor (the fp32 gradient tolerance of the other tests), or
+          belongs to a Q2 bias, whose whole gradient is below 1e-5 of the global gradient norm;
+      (2) the second-step loss equals the oracle's second-step loss plus the FIRST-ORDER effect of exactly those moves,
+          L2_ref + <dL2/dp (oracle), p1_hip - p1_ref>, to 2e-4 relative -- the remaining second-order term; the loss terms
+          of the first step agree to 1e-4 (north_star's tolerance)."""
+    y = api()
+    torch.manual_seed(0)
+    ref = y.YOLO(num_classes=nc, img_size=S)
+    P = {k: v.clone() for k, v in ref.state_dict().items()}
+    names = [n for n, _ in ref.named_parameters()]
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(91))
+    tg = y.synthetic_targets(B, nc, S, 8, 92)
+    # oracle: step 1 (clip 10 + Adam), then loss and gradient at the updated point
+    for n in names:
+        P[n].requires_grad_(True)
+    l1 = orc.loss_multiscale(orc.forward(P, x, nc, True), tg, orc.anchors_of(P), nc)
+    l1[0].backward()
+    g1 = {n: P[n].grad.clone() for n in names}
+    total, coef = orc.clip_coef([g1[n] for n in names], 10.0)
+    p0 = {n: P[n].detach().clone() for n in names}
+    with torch.no_grad():
+        for n in names:
+            orc.adam_step(P[n], g1[n] * coef, torch.zeros_like(P[n]), torch.zeros_like(P[n]), 1, 1e-3)
+            P[n].grad = None
+    l2 = orc.loss_multiscale(orc.forward(P, x, nc, True), tg, orc.anchors_of(P), nc)
+    l2[0].backward()
+    # HIP: two fused steps
+    m = ref.cuda()
+    tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
+    xg, tgg = x.cuda(), [t.cuda() for t in tg]
+    o1 = tr.step(xg, tgg)[:4].cpu().numpy().copy()
+    p1_hip = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+    o2 = tr.step(xg, tgg)[:4].cpu().numpy().copy()
+    close(o1, [float(v) for v in l1], 1e-4, 1e-6)
+    first_order, n_diff = 0.0, 0
+    for n in names:
+        d_hip, d_ref = p1_hip[n] - p0[n], P[n].detach() - p0[n]
+        diff = (d_hip - d_ref).abs() > 1e-5                               # more than 1 % of lr apart
+        if bool(diff.any()):
+            if n in Q2:      # the whole tensor is rounding noise (true gradient 0): negligible against the global norm
+                assert float(g1[n].abs().max()) <= 1e-5 * total, n
+            else:
+                assert float(g1[n].abs()[diff].max()) <= 2e-3 * float(g1[n].abs().max()) + 1e-12, n   # claim (1)
+            n_diff += int(diff.sum())
+        first_order += float(((p1_hip[n] - P[n].detach()).double() * P[n].grad.double()).sum())
+    assert n_diff > 0                                                    # the effect exists (else the golden test could be 1e-4)
+    want2 = float(l2[0]) + first_order
+    assert abs(float(o2[0]) - want2) <= 2e-4 * abs(float(l2[0])), (float(o2[0]), float(l2[0]), first_order)   # claim (2)
 
 
 def test_training_step_is_bitwise_reproducible():
@@ -292,17 +352,62 @@ def test_inference_session_graph_replay_matches_eager_and_oracle():
         assert len(de) > 5 and de == dg
         with torch.no_grad():
             preds = orc.forward(P, img, 3, training=False)
-        b, s, c = orc.candidates(preds, orc.anchors_of(P), 320, 3, 0.3, lb[0], lb[1], lb[2])
-        M = int(graph.det.count.item())
-        assert abs(M - len(s)) <= max(2, len(s) // 100)              # cells within an ulp of the threshold may flip
-        keep = orc.nms_batched(graph.det.boxes[:M].cpu().numpy(), graph.det.scores[:M].cpu().numpy(),
-                               graph.det.classes[:M].cpu().numpy(), 0.4)
-        got = graph.det.keep[: int(graph.det.nkeep.item())].cpu().numpy()
-        np.testing.assert_array_equal(got, keep)
         with torch.no_grad():
             hip_preds = m(img.cuda())
         for a, r in zip(hip_preds, preds):
             assert float((a.cpu() - r).abs().max()) < 2e-3 * max(1.0, float(r.abs().max()))
+        # kept indices bit-exact on the GPU's own candidates, and every difference to the oracle pipeline accounted for
+        # (threshold cells, IoU pairs straddling the NMS threshold): tests/nms_explain.py
+        from nms_explain import explain_detections
+        explain_detections(graph.det, hip_preds, preds, orc.anchors_of(P), 320, 3, 0.3, 0.4, lb)
+
+
+def test_predict_batch_matches_oracle_pipeline_per_image(tmp_path):
+    """predict_batch (one batched forward, per-image candidate / NMS segments) against the ORACLE pipeline run image by
+    image -- letterbox, eval forward, candidates, class-aware NMS (train.py:1114-1250) -- not against predict()."""
+    from PIL import Image
+    from nms_explain import explain_detections
+    y = api()
+    nc, S = 2, 320
+    torch.manual_seed(13)
+    m = y.YOLO(num_classes=nc, img_size=S)
+    m.initialize_detection_biases(prior=0.3)
+    with torch.no_grad():
+        for hd in (m.head_p3, m.head_p4, m.head_p5):
+            hd[-1].weight.mul_(25.0)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.8, 1.2); mod.bias.uniform_(-0.1, 0.1)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    rng = np.random.default_rng(3)
+    paths = []
+    for k, (h, w) in enumerate(((200, 300), (320, 320), (400, 250), (90, 333))):
+        pth = tmp_path / f"im{k}.png"
+        Image.fromarray((rng.random((h, w, 3)) * 255).astype(np.uint8)).save(pth)
+        paths.append(str(pth))
+    dets = y.predict_batch(m, paths, torch.device("cuda"), num_classes=nc, conf_threshold=0.3, iou_threshold=0.4)
+    assert len(dets) == len(paths)
+    total_kept = 0
+    for b, pth in enumerate(paths):
+        pil, scale, pad_top, pad_left = y.letterbox_resize(Image.open(pth).convert("RGB"), S)
+        x = (torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0).unsqueeze(0)
+        with torch.no_grad():
+            ref = orc.forward(P, x, nc, training=False)
+            hip = m(x.cuda())
+        det = m._detectors[b]
+        explain_detections(det, hip, ref, orc.anchors_of(P), S, nc, 0.3, 0.4, (pad_left, pad_top, scale))
+        # the returned tuples are the kept candidates, in order, in original-image pixels
+        k = int(det.nkeep.item())
+        idx = det.keep[:k].long()
+        assert len(dets[b]) == k
+        got = np.array([d[:5] for d in dets[b]], np.float32).reshape(-1, 5)
+        np.testing.assert_array_equal(got[:, :4], det.boxes[idx].cpu().numpy())
+        np.testing.assert_array_equal(got[:, 4], det.scores[idx].cpu().numpy())
+        assert [d[5] for d in dets[b]] == det.classes[idx].cpu().tolist()
+        total_kept += k
+    assert total_kept > 20
 
 
 def test_side_lanes_do_not_change_results_and_trajectory_tracks_oracle():
