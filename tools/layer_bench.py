@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--img", type=int, default=640)
     ap.add_argument("--nc", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     args = ap.parse_args()
     import yolo_from_scratch_amd as y
     from yolo_from_scratch_amd import _lib as L
@@ -30,7 +31,7 @@ def main():
     torch.manual_seed(0)
     model = y.YOLO(num_classes=args.nc, img_size=args.img).to(dev).train()
     x = torch.rand(args.batch, 3, args.img, args.img, device=dev)
-    tr = y.HipTrainer(model)
+    tr = y.HipTrainer(model, dtype=args.dtype)
     tg = [t.to(dev) for t in y.synthetic_targets(args.batch, args.nc, args.img)]
     tr.step(x, tg)                       # populate every buffer
     plan = model._plan_for(x)
@@ -55,11 +56,14 @@ def main():
 
     fa, fn = plan.fwd_ops
     ba, bn = plan.bwd_ops
-    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD})
-    DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA, L.OP_CONV_BWD_DATA_S2M}
-    tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT})
-    other_f = time_ops(fa, fn, {L.OP_BN_SILU_FWD, L.OP_BN_FINALIZE, L.OP_PACK_WEIGHTS, L.OP_MAXPOOL5_FWD})
-    other_b = time_ops(ba, bn, {L.OP_BN_SILU_BWD_REDUCE, L.OP_BN_SILU_BWD_APPLY, L.OP_COLSUM, L.OP_MAXPOOL5_BWD})
+    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD, L.OP_BF16_CONV_FWD})
+    DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA, L.OP_CONV_BWD_DATA_S2M,
+          L.OP_BF16_CONV_BWD_DATA}
+    tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT, L.OP_BF16_CONV_BWD_WEIGHT})
+    other_f = time_ops(fa, fn, {L.OP_BN_SILU_FWD, L.OP_BN_FINALIZE, L.OP_PACK_WEIGHTS, L.OP_MAXPOOL5_FWD, L.OP_BF16_BN_SILU_FWD,
+                                L.OP_BF16_MAXPOOL5_FWD, L.OP_BF16_PACK_MULTI})
+    other_b = time_ops(ba, bn, {L.OP_BN_SILU_BWD_REDUCE, L.OP_BN_SILU_BWD_APPLY, L.OP_COLSUM, L.OP_MAXPOOL5_BWD,
+                                L.OP_BF16_BN_SILU_BWD_REDUCE, L.OP_BF16_BN_SILU_BWD_APPLY, L.OP_BF16_COLSUM, L.OP_BF16_MAXPOOL5_BWD})
 
     def desc(o):
         i = o.i
@@ -67,7 +71,10 @@ def main():
             return (i[3], i[4], i[5], i[6], i[7] + i[9], 1, 1)
         if o.kind == L.OP_CONV_PW_BWD_DATA:
             return (i[5], i[6], i[7], i[8], i[0], 1, 1)
-        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD, L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_DATA_S2M):
+        if o.kind == L.OP_BF16_CONV_BWD_DATA and i[11] > 0:       # fused sibling pair: listed under the first conv's shape
+            return (i[3], i[4], i[5], i[6], i[11], 1, 1)
+        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_STEM_FWD, L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_DATA_S2M,
+                      L.OP_BF16_CONV_FWD, L.OP_BF16_CONV_BWD_DATA):
             return (i[3], i[4], i[5], i[6], i[7], i[8], i[9])
         if o.kind == L.OP_CONV_WINO_BWD_DATA:
             return (i[3], i[4], i[5], i[6], i[7], 3, 1)
@@ -82,7 +89,8 @@ def main():
     for k, ms in tb.items():
         d = desc(ba[k])
         rows.setdefault(d, [0.0, 0.0, 0.0, 0])[1 if ba[k].kind in DG else 2] += ms
-    print(f"{'B,H,W,Cin,Cout,k,s':32s} {'n':>2s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
+    esz = 2 if args.dtype == "bf16" else 4
+    print(f"{'B,H,W,Cin,Cout,k,s':32s} {'n':>2s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s} | in+out MB, fwd TB/s")
     tot = [0.0, 0.0, 0.0, 0.0]
     for d, (f, dg, wg, cnt) in sorted(rows.items(), key=lambda kv: -(kv[1][0] + kv[1][1] + kv[1][2])):
         B, H, W, Cin, Cout, k, s = d
@@ -90,12 +98,15 @@ def main():
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         gf = 2.0 * B * Ho * Wo * Cin * Cout * k * k * cnt / 1e9
         tfs = lambda ms: gf / ms if ms > 0 else 0.0
-        print(f"{str(d):32s} {cnt:2d} {gf:8.2f} | {f:8.3f} {tfs(f):6.1f} | {dg:8.3f} {tfs(dg):6.1f} | {wg:8.3f} {tfs(wg):6.1f}")
+        mb = cnt * B * (H * W * Cin + Ho * Wo * Cout) * esz / 1e6
+        print(f"{str(d):32s} {cnt:2d} {gf:8.2f} | {f:8.3f} {tfs(f):6.1f} | {dg:8.3f} {tfs(dg):6.1f} | {wg:8.3f} {tfs(wg):6.1f} | {mb:7.0f} {mb / 1e3 / f if f > 0 else 0:5.2f}")
         tot[0] += f; tot[1] += dg; tot[2] += wg; tot[3] += gf
     print(f"{'TOTAL':32s}    {tot[3]:8.2f} | {tot[0]:8.3f} {tot[3] / tot[0]:6.1f} | {tot[1]:8.3f} {tot[3] / max(tot[1], 1e-9):6.1f} | {tot[2]:8.3f} {tot[3] / tot[2]:6.1f}")
     names = {L.OP_BN_SILU_FWD: "bn_silu_fwd", L.OP_BN_FINALIZE: "bn_finalize", L.OP_PACK_WEIGHTS: "pack_weights",
              L.OP_MAXPOOL5_FWD: "maxpool_fwd", L.OP_BN_SILU_BWD_REDUCE: "bn_bwd_reduce", L.OP_BN_SILU_BWD_APPLY: "bn_bwd_apply",
-             L.OP_COLSUM: "colsum", L.OP_MAXPOOL5_BWD: "maxpool_bwd"}
+             L.OP_COLSUM: "colsum", L.OP_MAXPOOL5_BWD: "maxpool_bwd", L.OP_BF16_BN_SILU_FWD: "bn_silu_fwd", L.OP_BF16_MAXPOOL5_FWD: "maxpool_fwd",
+             L.OP_BF16_PACK_MULTI: "pack_weights", L.OP_BF16_BN_SILU_BWD_REDUCE: "bn_bwd_reduce", L.OP_BF16_BN_SILU_BWD_APPLY: "bn_bwd_apply",
+             L.OP_BF16_COLSUM: "colsum", L.OP_BF16_MAXPOOL5_BWD: "maxpool_bwd"}
     agg = {}
     for arr, res in ((fa, other_f), (ba, other_b)):
         for k, ms in res.items():

@@ -108,8 +108,10 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     __syncthreads();
 
     const int cin8 = g.Cin >> 3;
-    u32x4 ra[AROWS], rb[BPASS];
-    auto load_tiles = [&](int c) {
+    // two register sets: the loads of chunks c+1 and c+2 are both in flight while chunk c is multiplied (the layers are
+    // latency-bound at bf16 MFMA rates: a chunk's 16 MFMAs take ~0.25 us, a global load ~1-2 us)
+    u32x4 raA[AROWS], rbA[BPASS], raB[AROWS], rbB[BPASS];
+    auto load_tiles = [&](int c, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS]) {
         const int k = c * BK + 8 * kq;
         if (k < g.Ktot) {
             int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS]) {
         unsigned char *a = As + buf * BM * A_STRIDE;
         unsigned char *b = Bs + buf * 8 * BN * 16;
 #pragma unroll
@@ -176,14 +178,21 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     };
-    // register-staged double buffer: the loads of chunk c+1 are in flight while chunk c is multiplied
-    load_tiles(0);
-    store_tiles(0);
+    // software pipeline, prefetch distance 2: at step c the loads of chunk c+2 are issued, chunk c is multiplied from LDS,
+    // then chunk c+1 (loaded one step earlier) is written to the other LDS buffer
+    load_tiles(0, raA, rbA);
+    store_tiles(0, raA, rbA);
+    if (nchunks > 1) load_tiles(1, raB, rbB);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) load_tiles(c + 1);
-        compute(c & 1, g.Ktot - c * BK);
-        if (c + 1 < nchunks) store_tiles((c + 1) & 1);
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) load_tiles(c + 2, raA, rbA);
+        compute(0, g.Ktot - c * BK);
+        if (c + 1 < nchunks) store_tiles(1, raB, rbB);
+        __syncthreads();
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) load_tiles(c + 3, raB, rbB);
+        compute(1, g.Ktot - (c + 1) * BK);
+        if (c + 2 < nchunks) store_tiles(0, raA, rbA);
         __syncthreads();
     }
 
@@ -524,9 +533,24 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const BfWgrad g) {
     }
     __syncthreads();
 
-    // ---- slab write: sum the WK pixel groups through LDS, then [tap][ci][co] fp32 ----------------------------------
-    float *red = (float *)smem;              // [WI*WJ][KK][32][33]
+    // ---- slab write: [tap][ci][co] fp32 ---------------------------------------------------------------------------------
+    float *slab = g.ws + (size_t)blockIdx.x * KK * g.Cin * g.Cout;
     const int lr = lane & 31;
+    if (WK == 1) {
+        // every wave owns its 32 x 32 block outright: straight from the accumulators (a register row = 32 consecutive output
+        // channels = one 128-byte store per half wave); no LDS, so the kernel's LDS footprint is the staging tiles only
+        const int co = co0 + 32 * wj + lr;
+#pragma unroll
+        for (int u = 0; u < KK; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ci = ci0 + 32 * wi + mfma_row(q, lh);
+                if (ci < g.Cin && co < g.Cout) slab[((size_t)u * g.Cin + ci) * g.Cout + co] = acc[u][q];
+            }
+        return;
+    }
+    // WK > 1 (narrow layers): the pixel groups are summed through LDS in a fixed order first
+    float *red = (float *)smem;              // [WI*WJ][KK][32][33]
     for (int wsel = WK - 1; wsel >= 0; --wsel) {
         if (wk == wsel) {
             float *r = red + (size_t)((wj * WI + wi) * KK) * 32 * 33;
@@ -540,7 +564,6 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const BfWgrad g) {
         }
         __syncthreads();
     }
-    float *slab = g.ws + (size_t)blockIdx.x * KK * g.Cin * g.Cout;
     const int total = KK * CIT * COT;
     for (int i = t; i < total; i += 256) {
         const int co_l = i % COT;
@@ -554,10 +577,6 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const BfWgrad g) {
     }
 }
 
-// fixed-order sum of the slabs -> OIHW fp32 (cin_real input channels).  A workgroup owns 16 consecutive slab elements;
-// its 16 split-lanes each add the slabs k = lane, lane + 16, ... in order, then the 16 partial sums are combined in a
-// fixed order: deterministic, and 16x more loads in flight than one thread per element (the small layers have 1024
-// slabs of a few thousand elements: a serial walk per element was 3.9 ms per step of pure latency).
 template <int E>      // E elements x (256 / E) split-lanes per workgroup: 16 x 16 for many slabs, 64 x 4 for few
 __global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float *__restrict__ ws, int nsplit, int KK, int Cin, int cin_real,
                                                                 int Cout, float *__restrict__ dw) {
@@ -616,11 +635,12 @@ int plan_wgrad(WgradPlan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, i
     g.dstride = COT == 32 ? 64 : 192;
     const int XW = (g.P - 1) * s + k;
     const size_t stage = (size_t)k * XW * g.xstride + (size_t)g.P * g.dstride;
-    const size_t red = (size_t)pl.WI * pl.WJ * pl.KK * 32 * 33 * sizeof(float);
+    const size_t red = pl.WI * pl.WJ == 4 ? 0 : (size_t)pl.WI * pl.WJ * pl.KK * 32 * 33 * sizeof(float);   // only when waves split pixels
     pl.smem = stage > red ? stage : red;
     YH_REQUIRE(pl.smem <= 160 * 1024, "bf16_wgrad: LDS footprint %zu too large", pl.smem);
-    // split count: ~1024 workgroups per layer (HBM-bound: enough to fill the chip several times over)
-    static const int target = getenv("YH_BF16_WGRAD_BLOCKS") ? atoi(getenv("YH_BF16_WGRAD_BLOCKS")) : 1024;
+    // split count: one workgroup per CU -- every workgroup pays a fixed epilogue (its whole [taps][ci][co] slab through LDS to
+    // HBM, then the reduction re-reads it): with 1024 splits the 3x3 layers moved 300 MB of slabs each, 5.8 ms per step
+    static const int target = getenv("YH_BF16_WGRAD_BLOCKS") ? atoi(getenv("YH_BF16_WGRAD_BLOCKS")) : 256;
     int want = target / pl.ntiles;
     if (want < 1) want = 1;
     if (want > g.nseg_total) want = g.nseg_total;
