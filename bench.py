@@ -28,6 +28,8 @@ if os.environ.get("YH_BENCH_SHAPE"):
     NC, IMG, BATCH = (int(v) for v in os.environ["YH_BENCH_SHAPE"].split(","))
 # YH_BENCH_DTYPE=bf16: the bf16 path of configs 3-4 (informational too: the headline line is fp32, the reference's arithmetic)
 DTYPE = os.environ.get("YH_BENCH_DTYPE", "f32")
+# YH_BENCH_SIZE=n|s|m|l|x: the reference's other model sizes (train.py:1346-1352), informational as well
+SIZE = os.environ.get("YH_BENCH_SIZE", "s")
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md, HBM3E spec (6290 measured with a float4 copy)
 
@@ -79,7 +81,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD, L.OP_BF16_CONV_FWD):
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD, L.OP_BF16_CONV_FWD, L.OP_CONV_NARROW):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
@@ -115,13 +117,29 @@ def host_cores():
     return n
 
 
+def stored_traffic():
+    """HBM bytes of the forward-convolution launches from the committed rocprofv3 PMC profile -- quoted only when the profile
+    was taken on exactly these kernels (tools/provenance.py: hash of csrc/ + the C header); otherwise null."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from provenance import csrc_hash
+    path = os.path.join(ROOT, "profiles", f"r02_step_profile_{DTYPE}.json")
+    if not os.path.exists(path) or (NC, IMG, BATCH, SIZE) != ((1, 640, 64, "s") if DTYPE == "f32" else (80, 640, 64, "s")):
+        return None, f"no committed PMC profile for this workload ({os.path.basename(path)})"
+    doc = json.load(open(path))
+    if doc.get("stamp", {}).get("csrc_sha16") != csrc_hash():
+        return None, f"{os.path.basename(path)} was taken on other kernels (csrc hash {doc.get('stamp', {}).get('csrc_sha16')} != {csrc_hash()}): not quoted"
+    return doc["groups"]["fwd_conv"]["hbm_bytes_per_step"], (
+        f"HBM-side bytes per step over the forward-convolution launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(path)}, "
+        f"tools/step_profile.py, stamp {doc['stamp']})")
+
+
 def cpu_baseline(batch=8, steps=3):
     """The CPU oracle's training step (same math on stock torch CPU ops) on a bounded sample."""
     from oracle import yolo_oracle as orc
     import yolo_from_scratch_amd as y
     torch.set_num_threads(host_cores())       # oversubscribing the quota is several times slower
     torch.manual_seed(0)
-    m = y.YOLO(num_classes=NC, img_size=IMG)
+    m = y.YOLO(num_classes=NC, img_size=IMG, width_mult=y.YOLO_SIZES[SIZE][0], depth_mult=y.YOLO_SIZES[SIZE][1])
     P = {k: v.clone() for k, v in m.state_dict().items()}
     params = [P[n].requires_grad_(True) for n, _ in m.named_parameters()]
     opt = torch.optim.Adam(params, lr=1e-3)
@@ -193,7 +211,7 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(0)                                   # identical replicas
-    model = y.YOLO(num_classes=NC, img_size=IMG).to(dev)
+    model = y.YOLO(num_classes=NC, img_size=IMG, width_mult=y.YOLO_SIZES[SIZE][0], depth_mult=y.YOLO_SIZES[SIZE][1]).to(dev)
     trainer = y.HipTrainer(model, lr=1e-3, max_norm=10.0, dtype=DTYPE)
     imgs = torch.rand(BATCH, 3, IMG, IMG, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
     targets = [t.to(dev) for t in y.synthetic_targets(BATCH, NC, IMG, 8, 2000 + rank)]
@@ -218,12 +236,12 @@ def main():
     loss = trainer.loss_out[:4].tolist()
 
     result = {
-        "metric": "images/sec training step, 640x640 bs=64/GPU" if (NC, IMG, BATCH, DTYPE) == (1, 640, 64, "f32") else
-                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} {DTYPE} (informational shape)", "value": round(BATCH * world * args.steps / elapsed, 2),
+        "metric": "images/sec training step, 640x640 bs=64/GPU" if (NC, IMG, BATCH, DTYPE, SIZE) == (1, 640, 64, "f32", "s") else
+                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} {DTYPE} size {SIZE} (informational shape)", "value": round(BATCH * world * args.steps / elapsed, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-        "config": {"workload": f"nc={NC} {IMG}x{IMG} bs={BATCH}/GPU full training step (fwd+loss+bwd+clip10+Adam), model size s, "
+        "config": {"workload": f"nc={NC} {IMG}x{IMG} bs={BATCH}/GPU full training step (fwd+loss+bwd+clip10+Adam), model size {SIZE}, "
                                + ("fp32 MFMA" if DTYPE == "f32" else "bf16 MFMA convolutions, bf16 activations, fp32 master weights / statistics / loss"),
                    "global_batch": BATCH * world, "parallelism": f"dp{world}"},
         "loss": [round(v, 6) for v in loss],
@@ -239,7 +257,7 @@ def main():
         ach = nbytes / (conv_ms * 1e-3) / 1e9
         bn_ms = per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BF16_BN_SILU_FWD, 0.0)
         result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                              "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": stored_traffic()[0], "traffic_note": stored_traffic()[1],
                               "kernel": "forward convolutions: bf16_gemm_kernel (gather implicit GEMM on v_mfma_f32_32x32x16_bf16)",
                               "kernel_ms_per_step": round(conv_ms, 3), "launches_per_step": n_launch,
                               "algorithmic_gbytes_per_step": round(nbytes / 1e9, 3),
@@ -255,17 +273,14 @@ def main():
         conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
         flops, flops_wino = (v * BATCH for v in plan_conv_flops(plan))
         ach = flops / (conv_ms * 1e-3) / 1e12
-        traffic = None          # HBM bytes of the same 62 launches, from the committed rocprofv3 PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+        traffic, traffic_note = stored_traffic()
         result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "traffic_note": "HBM-side bytes per step over the same forward-convolution launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                                              "profiles/r01_hbm_traffic.json, tools/hbm_traffic.py); algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
-                              "kernel": "forward convolutions: wino_kernel (22 3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
-                                        "the algorithmic multiplies) + pw_gemm_kernel (1x1) + gather_gemm_kernel (stride-2, "
-                                        "wide 1x1, head outputs) + stem_conv_kernel (first layer, VALU)",
+                              "traffic_note": traffic_note + "; algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
+                              "kernel": "forward convolutions: wino_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
+                                        "the algorithmic multiplies) + pw_gemm_kernel / pw_stream_kernel (1x1) + gather_gemm_kernel (stride-2, "
+                                        "wide 1x1, head outputs) + narrow_conv_kernel (16-channel 3x3 layers, stem[3]) + stem_conv_kernel (first layer, VALU)",
+                              "narrow_ms_per_step": round(per_kind.get(L.OP_CONV_NARROW, 0.0), 3),
                               "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
                               "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
                               "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0) + per_kind.get(L.OP_CONV_PW_FWD2, 0.0), 3),
@@ -286,6 +301,9 @@ def main():
         result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items(), key=lambda kv: str(kv[0]))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+        if (IMG, SIZE) == (640, "s"):       # BASELINE configs[0]: the reference's own CPU-runnable case, batch 2
+            b2 = cpu_baseline(batch=2, steps=5)
+            result["cpu_baseline"]["config1_batch2"] = {"value": b2["value"], "unit": b2["unit"], "sample": b2["sample"]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -130,6 +130,22 @@ int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cou
 int yh_conv_stem_fwd(const float *x, const float *wf, const float *bias, float *y, int ldy, float *bn_partials, int B, int Hi,
                      int Wi, void *stream);
 int yh_conv_stem_blocks(int B, int Hi, int Wi);
+/* The narrow high-resolution 3x3 layers (16 -> 16 stride 1: the C3 bottleneck at 1/4 resolution; 16 -> 32 stride 2: stem[3]) as
+ * a direct convolution on v_mfma_f32_16x16x4_f32: the input halo patch is read from HBM once into LDS, the whole filter sits
+ * in registers, 16-wide MFMA tiles (no padding of the 16 output channels).  w: the forward pack [9][Cin][ldw] of
+ * yh_pack_weights(_multi); with flip_taps = 1 and the BACKWARD pack [9][Cout][ldw] it computes the stride-1 input gradient
+ * (then x = dY, Cin / Cout = the convolution's Cout / Cin).  Same results and bn_partials contract as yh_conv_fwd
+ * ([yh_conv_narrow_blocks(...)][2][Cout]).  replaces: train.py:300-306 (Bottleneck convs), 407 (stem[3]), 913. */
+int yh_conv_narrow_ok(int Cin, int Cout, int k, int s);
+int yh_conv_narrow_blocks(int B, int Hi, int Wi, int s);
+int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy, float *bn_partials, int B,
+                   int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream);
+/* Input gradient of the stride-2 narrow layer (stem[3], Cin = 16, Cout = 32) as a direct kernel: one MFMA tile = 16 dX pixels
+ * of one (row, column) parity class, which receive 1, 2, 2 or 4 taps -- no zero-stuffed taps, dY read from HBM once.  wb: the
+ * backward pack [9][Cout][ldwb]; Hi, Wi: the size of dX.  Same result as yh_conv_bwd_data(k = 3, s = 2). */
+int yh_conv_narrow_dgrad_s2_ok(int Cin, int Cout);
+int yh_conv_narrow_dgrad_s2(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi, int Wi, int Cin,
+                            int Cout, int accumulate, void *stream);
 /* Winograd F(2x2,3x3) path for 3x3 / stride-1 / pad-1 convolutions with even H, W and K % 16 == 0 (K = Cin forward,
  * Cout backward): the same results as yh_conv_fwd / yh_conv_bwd_data to fp32 rounding with 4/9 of the multiplies.
  * yh_wino_weights transforms OIHW weights into U[16][K][ldu] (backward = 0: K = Cin, N = Cout; backward = 1: the
@@ -390,7 +406,9 @@ enum {
     YH_OP_BF16_PACK_MULTI, YH_OP_BF16_CONV_FWD, YH_OP_BF16_CONV_BWD_DATA, YH_OP_BF16_CONV_BWD_WEIGHT, YH_OP_BF16_COLSUM,
     YH_OP_BF16_BN_SILU_FWD, YH_OP_BF16_BN_SILU_BWD_REDUCE, YH_OP_BF16_BN_SILU_BWD_APPLY, YH_OP_BF16_MAXPOOL5_FWD,
     YH_OP_BF16_MAXPOOL5_BWD,
-    YH_OP_FOLD_OIHW_MULTI, YH_OP_CONV_WINO_FWD_FUSED, YH_OP_CONV_PW_FWD_FUSED   /* slots of YH_OP_CONV_FWD_FUSED */
+    YH_OP_FOLD_OIHW_MULTI, YH_OP_CONV_WINO_FWD_FUSED, YH_OP_CONV_PW_FWD_FUSED,  /* slots of YH_OP_CONV_FWD_FUSED */
+    YH_OP_CONV_NARROW,  /* p: x, w, bias, y, partials;  i: ldx, ldw, ldy, B, H, W, Cin, Cout, s, flip_taps, accumulate */
+    YH_OP_CONV_NARROW_DGRAD_S2   /* slots of YH_OP_CONV_BWD_DATA */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

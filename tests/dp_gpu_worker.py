@@ -15,12 +15,14 @@ sys.path.insert(0, ROOT)
 
 def main():
     out, steps = sys.argv[1], int(sys.argv[2])
+    os.makedirs(out, exist_ok=True)
     dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
+    big = len(sys.argv) > 4 and sys.argv[4] == "big"          # profiling runs: a step long enough to see the overlap
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     import yolo_from_scratch_amd as y
     dev = torch.device("cuda:0")
-    nc, S, B = 1, 160, 2
+    nc, S, B = (1, 640, 16) if big else (1, 160, 2)
     torch.manual_seed(0 if rank == 0 else 12345)       # rank 1 starts from DIFFERENT weights: the broadcast must fix that
     m = y.YOLO(num_classes=nc, img_size=S).to(dev)
     kw = {} if dtype == "f32" else {"dtype": dtype}

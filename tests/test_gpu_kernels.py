@@ -377,3 +377,63 @@ def test_small_m_tap_split_inference_conv(B, H, W, Cin, Cout, s, res, up):
     assert torch.equal(y3, y2)
     assert lib.yh_conv_fwd_fused_splitk(*args, y3.data_ptr(), Cout, ws.data_ptr(), nws - 1, B, H, W, Cin, Cout, 3, s, 1, int(up), st) != 0
     assert lib.yh_conv_fwd_fused_ws(64, 160, 160, 32, 32, 3, 1) == 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 24, 64, 16, 16, 1), (3, 23, 45, 16, 16, 1), (2, 32, 96, 16, 32, 2), (2, 21, 67, 16, 32, 2),
+                                             (1, 8, 32, 16, 16, 1)])
+def test_narrow_direct_conv_kernel(B, H, W, Cin, Cout, s):
+    """yh_conv_narrow (LDS halo patch + register-resident filter on the 16x16x4 MFMA) = fp64 torch for the two narrow layer
+    shapes: forward with bias + BatchNorm partial sums into a channel slice of a wider buffer, ragged patches, and the
+    stride-1 backward-data form (flipped taps, backward pack, accumulate)."""
+    L = _lib()
+    lib = L.lib()
+    assert lib.yh_conv_narrow_ok(Cin, Cout, 3, s) == 1 and lib.yh_conv_narrow_ok(32, 32, 3, 1) == 0
+    torch.manual_seed(H * W + s)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), s, 1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    st = torch.cuda.current_stream().cuda_stream
+    ldx = Cin + 4
+    xbuf = torch.full((B, H, W, ldx), 9.0, device="cuda")
+    xbuf[..., 4:] = nhwc(x)
+    xv = xbuf.view(-1)[4:]
+    ldwf, ldwb = rup4(Cout), rup4(Cin)
+    wf = torch.empty(9 * Cin * ldwf, device="cuda")
+    wb = torch.empty(9 * Cout * ldwb, device="cuda")
+    L.check(lib.yh_pack_weights(w.cuda().data_ptr(), wf.data_ptr(), wb.data_ptr(), Cout, Cin, 3, Cin, ldwf, ldwb, st))
+    ldy = Cout + 8
+    ybuf = torch.full((B, Ho, Wo, ldy), 7.0, device="cuda")
+    yv = ybuf.view(-1)[4:]
+    nblk = lib.yh_conv_narrow_blocks(B, H, W, s)
+    part = torch.zeros(nblk * 2 * Cout, device="cuda")
+    L.check(lib.yh_conv_narrow(xv.data_ptr(), ldx, wf.data_ptr(), ldwf, bias.cuda().data_ptr(), yv.data_ptr(), ldy, part.data_ptr(),
+                               B, H, W, Cin, Cout, s, 0, 0, st), "narrow fwd")
+    y = ybuf[..., 4:4 + Cout].permute(0, 3, 1, 2)
+    assert rel_err(y, ref) < 1e-5
+    assert bool((ybuf[..., :4] == 7.0).all()) and bool((ybuf[..., 4 + Cout:] == 7.0).all())
+    ps = part.view(nblk, 2, Cout).double().sum(0).cpu()
+    assert rel_err(ps[0], ref.sum((0, 2, 3))) < 1e-4 and rel_err(ps[1], (ref * ref).sum((0, 2, 3))) < 1e-5
+    if s == 1:
+        dy = torch.randn(B, Cout, Ho, Wo)
+        want = F.conv_transpose2d(dy.double(), w.double(), None, 1, 1)
+        dx = torch.full((B, H, W, Cin), 1.0, device="cuda")
+        dyg = nhwc(dy)
+        L.check(lib.yh_conv_narrow(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, None, dx.data_ptr(), Cin, None, B, H, W, Cout, Cin, 1, 1, 0, st),
+                "narrow dgrad")
+        assert rel_err(dx.permute(0, 3, 1, 2), want) < 1e-5
+        L.check(lib.yh_conv_narrow(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, None, dx.data_ptr(), Cin, None, B, H, W, Cout, Cin, 1, 1, 1, st),
+                "narrow dgrad acc")
+        assert rel_err(dx.permute(0, 3, 1, 2), 2 * want) < 1e-5
+    else:       # stride 2: the parity-class backward-data kernel against conv_transpose2d and against the generic kernel
+        assert lib.yh_conv_narrow_dgrad_s2_ok(Cin, Cout) == 1
+        dy = torch.randn(B, Cout, Ho, Wo)
+        want = F.conv_transpose2d(dy.double(), w.double(), None, 2, 1, output_padding=(H + 2 - 3 - (Ho - 1) * 2, W + 2 - 3 - (Wo - 1) * 2))
+        dxbuf = torch.full((B, H, W, Cin + 4), 3.0, device="cuda")
+        dxv = dxbuf.view(-1)[4:]
+        dyg = nhwc(dy)
+        L.check(lib.yh_conv_narrow_dgrad_s2(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, dxv.data_ptr(), Cin + 4, B, H, W, Cin, Cout, 0, st), "dgrad s2")
+        assert rel_err(dxbuf[..., 4:].permute(0, 3, 1, 2), want) < 1e-5 and bool((dxbuf[..., :4] == 3.0).all())
+        L.check(lib.yh_conv_narrow_dgrad_s2(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, dxv.data_ptr(), Cin + 4, B, H, W, Cin, Cout, 1, st), "dgrad s2 acc")
+        assert rel_err(dxbuf[..., 4:].permute(0, 3, 1, 2), 2 * want) < 1e-5

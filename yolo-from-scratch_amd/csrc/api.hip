@@ -108,6 +108,12 @@ static int run_one(const yh_op &o, void *st) {
                                           (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], p[4], i[10], st);
         case YH_OP_NOP:
             return 0;
+        case YH_OP_CONV_NARROW:
+            return yh_conv_narrow((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
+                                  (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], st);
+        case YH_OP_CONV_NARROW_DGRAD_S2:    /* same argument slots as YH_OP_CONV_BWD_DATA */
+            return yh_conv_narrow_dgrad_s2((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4], i[5],
+                                           i[6], i[7], i[10], st);
         case YH_OP_FOLD_OIHW_MULTI:
             return yh_fold_oihw_multi(p[0], i[0], st);
         case YH_OP_CONV_WINO_FWD_FUSED:     /* slots of YH_OP_CONV_FWD_FUSED (k = 3, s = 1 implied) */

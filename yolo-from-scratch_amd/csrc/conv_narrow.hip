@@ -1,0 +1,279 @@
+// Direct 3x3 convolution for the NARROW, high-resolution layers (16 -> 16 at 160x160, 16 -> 32 stride 2 at 320x320):
+// fp32, NHWC, v_mfma_f32_16x16x4_f32.
+//
+// These layers carry little arithmetic per byte (24 .. 36 flop/B): they are HBM-bound, and on the 32-wide MFMA tiles of the
+// other convolution kernels half of every tile is padding (N = 16).  Here a workgroup owns a TH x 32 patch of output pixels:
+//   * the input halo patch is read from HBM ONCE, with 16-byte loads, into LDS laid out [channel quad][pixel][4] -- an A
+//     fragment of the 16x16x4 instruction (lane = pixel, k = 4 consecutive channels) is then one conflict-free
+//     ds_read_b32 per lane (64 consecutive floats per wave);
+//   * the whole filter (9 taps x CIN x COUT) lives in registers as B fragments, loaded once per workgroup;
+//   * 16 output pixels x 16 output channels per MFMA tile: no padding for N = 16, the full fp32 MFMA rate;
+//   * epilogue: bias, optional accumulate, 64-byte row stores, per-workgroup BatchNorm partial sums (fixed order).
+// The same kernel computes backward-data of a stride-1 layer (flipped taps, the backward weight pack).
+#include "common.h"
+
+namespace {
+
+struct Narrow {
+    const float *in, *w, *bias;     // w: [tap][CIN][ldw] (forward pack) or [tap][COUT_of_conv = K][ldw] (backward pack)
+    float *out, *stats;
+    int ldi, ldw, ldo;
+    int B, Hi, Wi, Ho, Wo;
+    int tiles_x, tiles_y;
+    int flip, accumulate;
+};
+
+template <int CIN, int COUT, int S>
+__global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
+    constexpr int TW = 32, TH = S == 1 ? 8 : 4;          // output patch
+    constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;
+    constexpr int Q = CIN / 4, NT = COUT / 16;
+    constexpr int MT = TH * 2 / 4;                        // 16-pixel row segments per wave (TH rows x 2 halves over 4 waves)
+    constexpr int NPX = IH * IW;
+    // stride 2: even and odd input columns are stored as two planes so that the 16 pixels of a fragment stay contiguous
+    constexpr int PLANE = S == 1 ? IW : (IW + 1) / 2;
+    __shared__ __attribute__((aligned(16))) float xs[Q * IH * (S == 1 ? IW : 2 * PLANE) * 4 + 4 * COUT * 2];
+    constexpr int ROWSZ = (S == 1 ? IW : 2 * PLANE);     // pixels per stored input row
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int tx = bid % g.tiles_x;
+    bid /= g.tiles_x;
+    const int ty = bid % g.tiles_y, b = bid / g.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+    // ---- stage the halo patch: one 16-byte piece = (pixel, channel quad) ------------------------------------------------
+    for (int i = t; i < NPX * Q; i += 256) {
+        const int q = i % Q, p = i / Q;
+        const int py = p / IW, px = p - py * IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
+            v = *(const f32x4 *)(g.in + ((size_t)(b * g.Hi + iy) * g.Wi + ix) * g.ldi + 4 * q);
+        const int sx = S == 1 ? px : (px & 1) * PLANE + (px >> 1);
+        *(f32x4 *)(xs + ((size_t)(q * IH + py) * ROWSZ + sx) * 4) = v;
+    }
+    // ---- the filter as B fragments: lane (col, kk) holds w[tap][4q + kk][n0 + col] ------------------------------------------
+    float bw[9 * Q][NT];
+#pragma unroll
+    for (int tq = 0; tq < 9 * Q; ++tq) {
+        const int tap = tq / Q, q = tq - tap * Q;
+        const int wt = g.flip ? 8 - tap : tap;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bw[tq][n] = g.w[((size_t)wt * CIN + 4 * q + kk) * g.ldw + 16 * n + col];
+    }
+    __syncthreads();
+
+    // ---- multiply: wave w owns output rows {w, w + 4} (stride 1: 8 rows) or row w (stride 2), two 16-pixel halves each -----
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int abase[MT];                                        // LDS float offset of the fragment's pixel `col` at tap (0,0), quad 0
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = wave + 4 * (m >> 1), half = m & 1;
+        const int px = (16 * half + col) * S;             // input column of this lane's pixel at tap dx = 0
+        const int sx = S == 1 ? px : (px >> 1);           // (even input column -> plane 0)
+        abase[m] = ((row * S) * ROWSZ + sx) * 4 + kk;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        // stride 2: dx = 0, 2 read the even plane at +0 / +1 pixel, dx = 1 the odd plane
+        const int doff = S == 1 ? (dy * ROWSZ + dx) * 4 : (dy * ROWSZ + (dx == 1 ? PLANE : (dx >> 1))) * 4;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float a[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = xs[q * IH * ROWSZ * 4 + abase[m] + doff];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[tap * Q + q][n], acc[m][n], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: D register r of lane (col, kk) = pixel 4 kk + r of the segment, channel col ------------------------------
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        csum[n] = csq[n] = 0.f;
+        const float bias = g.bias ? g.bias[16 * n + col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave + 4 * (m >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + 16 * (m & 1) + 4 * kk + r;
+                if (oy < g.Ho && ox < g.Wo) {
+                    float *o = g.out + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 16 * n + col;
+                    float v = acc[m][n][r] + bias;
+                    if (g.accumulate) v += *o;
+                    *o = v;
+                    csum[n] += v;
+                    csq[n] += v * v;
+                }
+            }
+        }
+    }
+    if (g.stats) {
+        float *red = xs + Q * IH * ROWSZ * 4;                      // [4 waves][COUT][2]
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            float s = csum[n], q = csq[n];
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (kk == 0) {
+                red[(wave * COUT + 16 * n + col) * 2 + 0] = s;
+                red[(wave * COUT + 16 * n + col) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < COUT) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * COUT + t) * 2]; q += red[(w * COUT + t) * 2 + 1]; }
+            g.stats[((size_t)blockIdx.x * 2 + 0) * COUT + t] = s;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * COUT + t] = q;
+        }
+    }
+}
+
+// Backward-data of the stride-2 layer (stem[3]: dY 32 channels at 160x160 -> dX 16 channels at 320x320), same ideas.
+// dX pixel (y, x) of parity (py, px) = (y & 1, x & 1), a = y >> 1, b = x >> 1, receives
+//   py = 0: kh = 1 from dY row a            py = 1: kh = 0 from row a + 1, kh = 2 from row a
+//   px = 0: kw = 1 from dY column b         px = 1: kw = 0 from column b + 1, kw = 2 from column b
+// i.e. 1, 2, 2 or 4 taps of 32 channels.  An MFMA tile is 16 dX pixels of ONE parity class in one row (x = 2 j + px), so the
+// tile shares its taps' weights; the A fragment (lane = j, k = 4 consecutive dY channels) is a conflict-free ds_read_b32 of
+// the staged dY patch.  A workgroup owns 8 dX rows x 64 columns; each wave takes one even and one odd row (balanced: 48 + 96
+// k-steps).  No zero-stuffed taps, no masked half tiles, every dY element read from HBM once.
+template <int KC, int NC>       // KC = dY channels (32), NC = dX channels (16)
+__global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
+    constexpr int TW = 64, TH = 8;                         // dX patch
+    constexpr int PW = TW / 2 + 1, PH = TH / 2 + 1;        // dY patch (one extra row / column for the +1 neighbours)
+    constexpr int Q = KC / 4;
+    __shared__ __attribute__((aligned(16))) float ds[Q * PH * PW * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % g.tiles_x;
+    bid /= g.tiles_x;
+    const int ty = bid % g.tiles_y, b = bid / g.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;                  // dX origin (even)
+    const int a0 = y0 >> 1, b0 = x0 >> 1;                  // dY origin
+    // g.Hi, g.Wi: dY size; g.Ho, g.Wo: dX size
+    for (int i = t; i < PH * PW * Q; i += 256) {
+        const int q = i % Q, p = i / Q;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int oy = a0 + pr, ox = b0 + pc;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (oy < g.Hi && ox < g.Wi) v = *(const f32x4 *)(g.in + ((size_t)(b * g.Hi + oy) * g.Wi + ox) * g.ldi + 4 * q);
+        *(f32x4 *)(ds + ((size_t)(q * PH + pr) * PW + pc) * 4) = v;
+    }
+    // weights: backward pack wb[tap][co][ldw] (K = co, N = ci); lane (col = ci, kk) holds w[tap][4q + kk][col]
+    float bw[9 * Q];
+#pragma unroll
+    for (int tq = 0; tq < 9 * Q; ++tq) {
+        const int tap = tq / Q, q = tq - tap * Q;
+        bw[tq] = g.w[((size_t)tap * KC + 4 * q + kk) * g.ldw + col];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {                       // this wave's even row (rr = 0) and odd row (rr = 1)
+        const int yl = 2 * wave + rr, y = y0 + yl, ar = yl >> 1;     // dY patch row of kh = 1 (even) / kh = 2 (odd)
+#pragma unroll
+        for (int pxp = 0; pxp < 2; ++pxp)
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg) {            // 16 pixels: x = x0 + 2 (16 seg + j) + pxp
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int jb = 16 * seg + col;             // dY patch column of the "+0" neighbour
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    if ((rr == 0) != (kh == 1)) continue;  // even rows: kh = 1; odd rows: kh = 0, 2
+                    const int prow = ar + (kh == 0 ? 1 : 0);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        if ((pxp == 0) != (kw == 1)) continue;
+                        const int pcol = jb + (kw == 0 ? 1 : 0);
+                        const float *ap = ds + ((size_t)prow * PW + pcol) * 4 + kk;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)q * PH * PW * 4], bw[(kh * 3 + kw) * Q + q], acc, 0, 0, 0);
+                    }
+                }
+                if (y < g.Ho) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int x = x0 + 2 * (16 * seg + 4 * kk + r) + pxp;
+                        if (x < g.Wo) {
+                            float *o = g.out + ((size_t)(b * g.Ho + y) * g.Wo + x) * g.ldo + col;
+                            float v = acc[r];
+                            if (g.accumulate) v += *o;
+                            *o = v;
+                        }
+                    }
+                }
+            }
+    }
+}
+
+int narrow_tiles(int Ho, int Wo, int s, int &tx, int &ty) {
+    const int TH = s == 1 ? 8 : 4;
+    tx = cdiv(Wo, 32);
+    ty = cdiv(Ho, TH);
+    return tx * ty;
+}
+
+}  // namespace
+
+extern "C" int yh_conv_narrow_ok(int Cin, int Cout, int k, int s) {
+    return k == 3 && ((Cin == 16 && Cout == 16 && s == 1) || (Cin == 16 && Cout == 32 && s == 2)) ? 1 : 0;
+}
+
+extern "C" int yh_conv_narrow_blocks(int B, int Hi, int Wi, int s) {
+    const int Ho = (Hi - 1) / s + 1, Wo = (Wi - 1) / s + 1;
+    int tx, ty;
+    return B * narrow_tiles(Ho, Wo, s, tx, ty);
+}
+
+extern "C" int yh_conv_narrow_dgrad_s2_ok(int Cin, int Cout) { return Cin == 16 && Cout == 32 ? 1 : 0; }
+
+extern "C" int yh_conv_narrow_dgrad_s2(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi, int Wi,
+                                       int Cin, int Cout, int accumulate, void *stream) {
+    YH_REQUIRE(dy && wb && dx && B > 0 && Hi > 0 && Wi > 0, "conv_narrow_dgrad_s2: bad argument");
+    YH_REQUIRE(yh_conv_narrow_dgrad_s2_ok(Cin, Cout), "conv_narrow_dgrad_s2: unsupported shape %d <- %d", Cin, Cout);
+    YH_REQUIRE(lddy >= Cout && lddy % 4 == 0 && ((uintptr_t)dy & 15) == 0 && lddx >= Cin && ldwb >= Cin, "conv_narrow_dgrad_s2: views must be 16-byte addressable");
+    Narrow g{};
+    g.in = dy; g.w = wb; g.out = dx; g.ldi = lddy; g.ldw = ldwb; g.ldo = lddx; g.B = B;
+    g.Ho = Hi; g.Wo = Wi;                                  // dX
+    g.Hi = (Hi - 1) / 2 + 1; g.Wi = (Wi - 1) / 2 + 1;      // dY
+    g.accumulate = accumulate ? 1 : 0;
+    g.tiles_x = cdiv(Wi, 64); g.tiles_y = cdiv(Hi, 8);
+    hipLaunchKernelGGL((narrow_dgrad_s2_kernel<32, 16>), dim3(B * g.tiles_x * g.tiles_y), dim3(256), 0, (hipStream_t)stream, g);
+    YH_CHECK_LAUNCH("conv_narrow_dgrad_s2");
+    return 0;
+}
+
+extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy,
+                              float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate,
+                              void *stream) {
+    YH_REQUIRE(x && w && y && B > 0 && Hi > 0 && Wi > 0, "conv_narrow: bad argument");
+    YH_REQUIRE(yh_conv_narrow_ok(Cin, Cout, 3, s), "conv_narrow: unsupported shape %d -> %d stride %d", Cin, Cout, s);
+    YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ldy >= Cout && ldw >= Cout, "conv_narrow: views must be 16-byte addressable");
+    YH_REQUIRE(!(flip_taps && s != 1), "conv_narrow: flipped taps (backward-data) only for stride 1");
+    Narrow g{};
+    g.in = x; g.w = w; g.bias = bias; g.out = y; g.stats = bn_partials;
+    g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.B = B; g.Hi = Hi; g.Wi = Wi;
+    g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
+    g.flip = flip_taps ? 1 : 0; g.accumulate = accumulate ? 1 : 0;
+    const int nt = narrow_tiles(g.Ho, g.Wo, s, g.tiles_x, g.tiles_y);
+    hipStream_t st = (hipStream_t)stream;
+    if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1>), dim3(B * nt), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2>), dim3(B * nt), dim3(256), 0, st, g);
+    YH_CHECK_LAUNCH("conv_narrow");
+    return 0;
+}

@@ -115,6 +115,8 @@ class ConvRec:
     pw_f: bool = False      # forward on the pointwise GEMM kernel
     stem_f: bool = False    # forward on the direct VALU kernel of the first layer
     s2m_b: bool = False     # stride-2 backward-data with the column parities merged into the channel axis
+    narrow_f: bool = False  # forward on the direct kernel for the narrow high-resolution 3x3 layers
+    narrow_b: bool = False  # stride-1 backward-data on the same kernel (flipped taps)
     fwd2: bool = False      # forward fused with the sibling pointwise conv (one GEMM, N = cout1 + cout2)
     nblk: int = 0           # BatchNorm partial-sum rows written by the forward kernel
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
@@ -266,6 +268,7 @@ class Plan:
         use_pwg = self.training and os.environ.get("YH_PWG", "1") != "0"
         use_stem = self.training and os.environ.get("YH_STEM", "1") != "0"
         use_s2m = self.training and os.environ.get("YH_S2M", "1") != "0"
+        use_narrow = self.training and os.environ.get("YH_NARROW", "1") != "0"
         s2m_packs: List[L.YhOp] = []
         pwpacks: List[tuple] = []              # k-quad interleaved weights of the pointwise GEMM kernels
         if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
@@ -358,6 +361,16 @@ class Plan:
                 r.s2m_b = use_s2m and r.k == 3 and r.s == 2 and r.need_dx and r.cin <= 16 and r.x.ld == r.cin and r.x.W % 2 == 0 \
                     and r.cin == r.weight.shape[1]
                 r.stem_f = use_stem and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16
+                # narrow high-resolution 3x3 layers: direct kernel (LDS halo patch, filter in registers, 16-wide MFMA tiles)
+                nar_ok = use_narrow and r.k == 3 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and r.x.off % 4 == 0
+                r.narrow_f = bool(nar_ok and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s))
+                r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
+                if r.narrow_f:
+                    r.wino_f = False
+                if r.narrow_b:
+                    r.wino_b = False
+                if nar_ok and r.s == 2 and r.need_dx and lib.yh_conv_narrow_dgrad_s2_ok(r.cin, r.cout):
+                    r.narrow_b, r.s2m_b = True, False      # the stride-2 form of the direct backward-data kernel
                 if r.pair is None:
                     r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
                 elif r.pair_first:
@@ -424,16 +437,23 @@ class Plan:
                         elif ln == 1 or q.lane == 1:
                             raise NotImplementedError("fused sibling convolution traced on the side lane without a preceding fork")
                 else:
-                    nblk = lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
+                    nblk = lib.yh_conv_narrow_blocks(r.x.B, r.x.H, r.x.W, r.s) if r.narrow_f else \
+                        lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
                         lib.yh_conv_pw_blocks(M, r.cin, r.cout) if r.pw_f else \
                         lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
                         lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                     alloc_out(r, nblk)
                     ytarget, ldy = (r.y, r.cout) if r.bn is not None else (None, r.out.ld)
-                    fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else (L.OP_CONV_STEM_FWD if r.stem_f else L.OP_CONV_FWD)),
-                                   p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
-                                      r.part if r.bn is not None else None],
-                                   i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
+                    if r.narrow_f:
+                        fwd.append(_op(L.OP_CONV_NARROW,
+                                       p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
+                                          r.part if r.bn is not None else None],
+                                       i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.s, 0, 0], lane=ln))
+                    else:
+                        fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else (L.OP_CONV_STEM_FWD if r.stem_f else L.OP_CONV_FWD)),
+                                       p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
+                                          r.part if r.bn is not None else None],
+                                       i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
                 nblk = r.nblk
                 if r.bn is not None:
                     track = r.bn.track_running_stats and r.bn.running_mean is not None
@@ -725,7 +745,13 @@ class Plan:
             elif r.need_dx:
                 dst, acc = self._grad_target(r.x)
                 writers.append((len(ops), r.x, r))
-                if r.s2m_b:
+                if r.narrow_b and r.s == 2:
+                    ops.append(_op(L.OP_CONV_NARROW_DGRAD_S2, p=[dy, r.wb, dst],
+                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
+                elif r.narrow_b:     # x = dY (Cout channels), output = dX (Cin channels), backward pack, flipped taps
+                    ops.append(_op(L.OP_CONV_NARROW, p=[dy, r.wb, None, dst, None],
+                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cout, r.cin, 1, 1, acc]))
+                elif r.s2m_b:
                     ops.append(_op(L.OP_CONV_BWD_DATA_S2M, p=[dy, r.wb, dst],
                                    i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
                 elif r.pw_b:
