@@ -4,6 +4,7 @@
 // workgroups; every cross-workgroup reduction is two-stage with a fixed summation order, so results
 // are bitwise reproducible run to run.
 #include "common.h"
+#include <initializer_list>
 
 namespace {
 
@@ -274,14 +275,32 @@ __device__ __forceinline__ float silu_grad(float z) {
     return s * (1.f + z * (1.f - s));
 }
 
-// a = silu(y*scale+shift) (+res); float4 over channels
-template <typename T>
+// Channel groups: G = 4 channels per thread and trip (fp32: one 16-byte access) or G = 8 (bf16 with C % 8 == 0: again one
+// 16-byte access -- 8-byte accesses reach only ~4 TB/s on these passes); all arithmetic in fp32.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int G> struct VecOf;
+template <> struct VecOf<4> { typedef f32x4 type; };
+template <> struct VecOf<8> { typedef f32x8 type; };
+template <int G> __device__ __forceinline__ typename VecOf<G>::type ldg(const float *p) { return *(const typename VecOf<G>::type *)p; }
+template <int G> __device__ __forceinline__ typename VecOf<G>::type ldg(const bf16 *p);
+template <> __device__ __forceinline__ f32x4 ldg<4>(const bf16 *p) { return __builtin_convertvector(*(const bf16x4 *)p, f32x4); }
+template <> __device__ __forceinline__ f32x8 ldg<8>(const bf16 *p) { return __builtin_convertvector(*(const bf16x8 *)p, f32x8); }
+template <int G> __device__ __forceinline__ void stg(float *p, typename VecOf<G>::type v) { *(typename VecOf<G>::type *)p = v; }
+__device__ __forceinline__ void stg4b(bf16 *p, f32x4 v) { *(bf16x4 *)p = __builtin_convertvector(v, bf16x4); }
+template <int G> __device__ __forceinline__ void stg(bf16 *p, typename VecOf<G>::type v);
+template <> __device__ __forceinline__ void stg<4>(bf16 *p, f32x4 v) { *(bf16x4 *)p = __builtin_convertvector(v, bf16x4); }
+template <> __device__ __forceinline__ void stg<8>(bf16 *p, f32x8 v) { *(bf16x8 *)p = __builtin_convertvector(v, bf16x8); }
+
+// a = silu(y*scale+shift) (+res); one channel group per thread and trip
+template <typename T, int G>
 __global__ void bn_silu_fwd_kernel(const T *__restrict__ y, int ldy, const float *__restrict__ coef,
                                    const T *__restrict__ res, int ldr, T *__restrict__ out, int ldo,
                                    int64_t M, int C, int H, int W, int upsample) {
-    // (row, channel-quad) cursor advanced incrementally: the grid-stride index i = m * cq + c4 is never divided inside
-    // the loop (a 64-bit division per float4 cost more VALU time than the four sigmoids)
-    const int cq = C >> 2;
+    typedef typename VecOf<G>::type V;
+    // (row, channel-group) cursor advanced incrementally: the grid-stride index i = m * cq + c4 is never divided inside
+    // the loop (a 64-bit division per group cost more VALU time than the sigmoids)
+    const int cq = C / G;
     const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     int64_t m = i0 / cq;
     int c4 = (int)(i0 - m * cq);
@@ -289,80 +308,83 @@ __global__ void bn_silu_fwd_kernel(const T *__restrict__ y, int ldy, const float
     const int dc = (int)(stride - dm * cq);
     for (; m < M; m += dm, c4 += dc) {
         if (c4 >= cq) { c4 -= cq; if (++m >= M) break; }
-        const int c = c4 << 2;
-        f32x4 v = ld4(y + m * ldy + c);
-        f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
-        f32x4 a;
+        const int c = c4 * G;
+        V v = ldg<G>(y + m * ldy + c);
+        V sc = *(const V *)(coef + c), sh = *(const V *)(coef + C + c);
+        V a;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = silu_f(v[e] * sc[e] + sh[e]);
+        for (int e = 0; e < G; ++e) a[e] = silu_f(v[e] * sc[e] + sh[e]);
         if (res) {
-            f32x4 r = ld4(res + m * ldr + c);
+            V r = ldg<G>(res + m * ldr + c);
             a += r;
         }
         if (!upsample) {
-            st4(out + m * ldo + c, a);
+            stg<G>(out + m * ldo + c, a);
         } else {
             const unsigned mu32 = (unsigned)m, q = mu32 / (unsigned)W, w = mu32 - q * (unsigned)W;      // M < 2^31
             const unsigned b = q / (unsigned)H, h = q - b * (unsigned)H;
             T *o = out + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldo + c;
-            st4(o, a);
-            st4(o + ldo, a);
-            st4(o + (size_t)2 * W * ldo, a);
-            st4(o + (size_t)2 * W * ldo + ldo, a);
+            stg<G>(o, a);
+            stg<G>(o + ldo, a);
+            stg<G>(o + (size_t)2 * W * ldo, a);
+            stg<G>(o + (size_t)2 * W * ldo + ldo, a);
         }
     }
 }
 
-template <typename T>
-__device__ __forceinline__ f32x4 load_da(const T *__restrict__ da, int ldda, int64_t m, int c, int H, int W,
-                                         int upsample) {
-    if (!upsample) return ld4(da + m * ldda + c);
+template <int G, typename T>
+__device__ __forceinline__ typename VecOf<G>::type load_da(const T *__restrict__ da, int ldda, int64_t m, int c, int H, int W,
+                                                          int upsample) {
+    if (!upsample) return ldg<G>(da + m * ldda + c);
     const unsigned mu32 = (unsigned)m, q = mu32 / (unsigned)W, w = mu32 - q * (unsigned)W;              // M < 2^31
     const unsigned b = q / (unsigned)H, h = q - b * (unsigned)H;
     const T *p = da + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * ldda + c;
-    f32x4 a = ld4(p), b1 = ld4(p + ldda);
-    f32x4 c1 = ld4(p + (size_t)2 * W * ldda), d1 = ld4(p + (size_t)2 * W * ldda + ldda);
+    typename VecOf<G>::type a = ldg<G>(p), b1 = ldg<G>(p + ldda);
+    typename VecOf<G>::type c1 = ldg<G>(p + (size_t)2 * W * ldda), d1 = ldg<G>(p + (size_t)2 * W * ldda + ldda);
     return (a + b1) + (c1 + d1);
 }
 
 // stage 1 of the backward: per-workgroup partial sums of dz and dz*xhat (per channel)
-template <typename T>
+template <typename T, int G>
 __global__ void bn_silu_bwd_reduce_kernel(const T *__restrict__ da, int ldda, const T *__restrict__ y,
                                           int ldy, const float *__restrict__ coef, float *__restrict__ part,
                                           int64_t M, int C, int H, int W, int upsample, int64_t rows_per_blk) {
-    extern __shared__ float red[];   // [256][8]
-    const int t = threadIdx.x, cq = C >> 2;
-    const int rg = 256 / cq;          // row groups (cq <= 64 -> rg >= 4); for cq > 256 not supported
+    typedef typename VecOf<G>::type V;
+    extern __shared__ float red[];   // [256][2 G]
+    const int t = threadIdx.x, cq = C / G;
+    const int rg = 256 / cq;          // row groups (cq <= 256)
     const int c4 = t % cq, r_in = t / cq;
     int64_t r0 = blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk;
     if (r1 > M) r1 = M;
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    V s1, s2;
+#pragma unroll
+    for (int e = 0; e < G; ++e) s1[e] = s2[e] = 0.f;
     if (r_in < rg) {
-        const int c = c4 << 2;
-        f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
-        f32x4 mu = *(const f32x4 *)(coef + 2 * C + c), is = *(const f32x4 *)(coef + 3 * C + c);
+        const int c = c4 * G;
+        V sc = *(const V *)(coef + c), sh = *(const V *)(coef + C + c);
+        V mu = *(const V *)(coef + 2 * C + c), is = *(const V *)(coef + 3 * C + c);
         int64_t m = r0 + r_in;
         for (; m + rg < r1; m += 2 * rg) {          // two rows per trip: four 16-byte loads in flight per thread
-            f32x4 yv0 = ld4(y + m * ldy + c), yv1 = ld4(y + (m + rg) * ldy + c);
-            f32x4 g0 = load_da(da, ldda, m, c, H, W, upsample), g1 = load_da(da, ldda, m + rg, c, H, W, upsample);
+            V yv0 = ldg<G>(y + m * ldy + c), yv1 = ldg<G>(y + (m + rg) * ldy + c);
+            V g0 = load_da<G>(da, ldda, m, c, H, W, upsample), g1 = load_da<G>(da, ldda, m + rg, c, H, W, upsample);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < G; ++e) {
                 float dz = g0[e] * silu_grad(yv0[e] * sc[e] + sh[e]);
                 s1[e] += dz;
                 s2[e] += dz * ((yv0[e] - mu[e]) * is[e]);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < G; ++e) {
                 float dz = g1[e] * silu_grad(yv1[e] * sc[e] + sh[e]);
                 s1[e] += dz;
                 s2[e] += dz * ((yv1[e] - mu[e]) * is[e]);
             }
         }
         for (; m < r1; m += rg) {
-            f32x4 yv = ld4(y + m * ldy + c);
-            f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
+            V yv = ldg<G>(y + m * ldy + c);
+            V g = load_da<G>(da, ldda, m, c, H, W, upsample);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < G; ++e) {
                 float dz = g[e] * silu_grad(yv[e] * sc[e] + sh[e]);
                 s1[e] += dz;
                 s2[e] += dz * ((yv[e] - mu[e]) * is[e]);
@@ -370,15 +392,17 @@ __global__ void bn_silu_bwd_reduce_kernel(const T *__restrict__ da, int ldda, co
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[t * 8 + e] = s1[e]; red[t * 8 + 4 + e] = s2[e]; }
+    for (int e = 0; e < G; ++e) { red[t * 2 * G + e] = s1[e]; red[t * 2 * G + G + e] = s2[e]; }
     __syncthreads();
     if (t < cq) {
-        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        V a, b;
+#pragma unroll
+        for (int e = 0; e < G; ++e) a[e] = b[e] = 0.f;
         for (int k = 0; k < rg; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] += red[(k * cq + t) * 8 + e]; b[e] += red[(k * cq + t) * 8 + 4 + e]; }
-        *(f32x4 *)(part + ((size_t)blockIdx.x * 2 + 0) * C + 4 * t) = a;
-        *(f32x4 *)(part + ((size_t)blockIdx.x * 2 + 1) * C + 4 * t) = b;
+            for (int e = 0; e < G; ++e) { a[e] += red[(k * cq + t) * 2 * G + e]; b[e] += red[(k * cq + t) * 2 * G + G + e]; }
+        *(V *)(part + ((size_t)blockIdx.x * 2 + 0) * C + G * t) = a;
+        *(V *)(part + ((size_t)blockIdx.x * 2 + 1) * C + G * t) = b;
     }
 }
 
@@ -405,13 +429,14 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk,
     }
 }
 
-template <typename T>
+template <typename T, int G>
 __global__ void bn_silu_bwd_apply_kernel(const T *__restrict__ da, int ldda, const T *__restrict__ y,
                                          int ldy, const float *__restrict__ coef, const float *__restrict__ dgamma,
                                          const float *__restrict__ dbeta, T *__restrict__ dy, int lddy,
                                          T *__restrict__ dres, int lddres, int res_acc, int64_t M, int C, int H,
                                          int W, int upsample) {
-    const int cq = C >> 2;
+    typedef typename VecOf<G>::type V;
+    const int cq = C / G;
     const float inv_n = 1.0f / (float)M;
     const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     int64_t m = i0 / cq;                       // division-free cursor, see bn_silu_fwd_kernel
@@ -420,24 +445,30 @@ __global__ void bn_silu_bwd_apply_kernel(const T *__restrict__ da, int ldda, con
     const int dc = (int)(stride - dm * cq);
     for (; m < M; m += dm, c4 += dc) {
         if (c4 >= cq) { c4 -= cq; if (++m >= M) break; }
-        const int c = c4 << 2;
-        f32x4 yv = ld4(y + m * ldy + c);
-        f32x4 g = load_da(da, ldda, m, c, H, W, upsample);
-        f32x4 sc = *(const f32x4 *)(coef + c), sh = *(const f32x4 *)(coef + C + c);
-        f32x4 mu = *(const f32x4 *)(coef + 2 * C + c), is = *(const f32x4 *)(coef + 3 * C + c);
-        f32x4 dg = *(const f32x4 *)(dgamma + c), db = *(const f32x4 *)(dbeta + c);
-        f32x4 o;
+        const int c = c4 * G;
+        V yv = ldg<G>(y + m * ldy + c);
+        V g = load_da<G>(da, ldda, m, c, H, W, upsample);
+        V sc = *(const V *)(coef + c), sh = *(const V *)(coef + C + c);
+        V mu = *(const V *)(coef + 2 * C + c), is = *(const V *)(coef + 3 * C + c);
+        V dg, db;                              // (views of the flat gradient buffer: 16-byte aligned only)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int h = 0; h < G; h += 4) {
+            const f32x4 g4 = *(const f32x4 *)(dgamma + c + h), b4 = *(const f32x4 *)(dbeta + c + h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dg[h + e] = g4[e]; db[h + e] = b4[e]; }
+        }
+        V o;
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
             float dz = g[e] * silu_grad(yv[e] * sc[e] + sh[e]);
             float xh = (yv[e] - mu[e]) * is[e];
             o[e] = sc[e] * (dz - db[e] * inv_n - xh * dg[e] * inv_n);
         }
-        st4(dy + m * lddy + c, o);
+        stg<G>(dy + m * lddy + c, o);
         if (dres) {
             T *r = dres + m * lddres + c;
-            if (res_acc) g += ld4(r);
-            st4(r, g);
+            if (res_acc) g += ldg<G>(r);
+            stg<G>(r, g);
         }
     }
 }
@@ -674,6 +705,18 @@ extern "C" int yh_bn_eval_coef(const float *gamma, const float *beta, const floa
     return 0;
 }
 
+// 8-channel groups (one 16-byte access per bf16 tensor): bf16 only, every channel count / stride a multiple of 8, every
+// view 16-byte aligned, and few enough groups per row for the reduce kernel's 256-thread layout
+template <typename T>
+static bool wide_groups(int C, std::initializer_list<int> lds, std::initializer_list<const void *> ptrs) {
+    if (sizeof(T) != 2 || C % 8 != 0 || C / 8 > 256) return false;
+    for (int ld : lds)
+        if (ld % 8 != 0) return false;
+    for (const void *p : ptrs)
+        if (((uintptr_t)p & 15) != 0) return false;
+    return true;
+}
+
 #define YH_REQ_VEC4(name, C, ...)                                                                     \
     YH_REQUIRE((C) % 4 == 0 && (C) <= 1024, name ": C=%d must be a multiple of 4 (<= 1024)", (C));       \
     do {                                                                                              \
@@ -687,8 +730,12 @@ static int bn_silu_fwd_t(const T *y, int ldy, const float *coef, const T *residu
     YH_REQUIRE(y && coef && out && M > 0 && M < (1ll << 31), "bn_silu_fwd: bad argument");
     YH_REQ_VEC4("bn_silu_fwd", C, ldy, ldo, residual ? ldr : 0);
     YH_REQUIRE(!upsample || (H > 0 && W > 0 && M % ((int64_t)H * W) == 0), "bn_silu_fwd: upsample needs H, W");
-    hipLaunchKernelGGL(bn_silu_fwd_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
-                       residual, ldr, out, ldo, M, C, H, W, upsample);
+    if (wide_groups<T>(C, {ldy, ldo, residual ? ldr : 0}, {y, out, residual}))
+        hipLaunchKernelGGL((bn_silu_fwd_kernel<T, 8>), dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
+                           residual, ldr, out, ldo, M, C, H, W, upsample);
+    else
+        hipLaunchKernelGGL((bn_silu_fwd_kernel<T, 4>), dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
+                           residual, ldr, out, ldo, M, C, H, W, upsample);
     YH_CHECK_LAUNCH("bn_silu_fwd");
     return 0;
 }
@@ -716,7 +763,9 @@ static int bn_silu_bwd_reduce_t(const T *da, int ldda, const T *y, int ldy, cons
     YH_REQUIRE(C <= 1024, "bn_silu_bwd_reduce: C too large");
     int nblk = yh_bn_bwd_blocks(M, C);
     int64_t rows = cdiv64(M, nblk);
-    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<T>, dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
+    // (8-channel groups measured SLOWER here -- 0.87 -> 1.01 ms per bf16 step: half as many row groups per workgroup and twice the
+    // sigmoid work per trip; the reduce keeps 4-channel groups for both storage types)
+    hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<T, 4>), dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
                        da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
     YH_CHECK_LAUNCH("bn_silu_bwd_reduce");
     return 0;
@@ -741,8 +790,12 @@ static int bn_silu_bwd_apply_t(const T *da, int ldda, const T *y, int ldy, const
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
                        C);
     YH_CHECK_LAUNCH("bn_bwd_finalize");
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,
-                       y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
+    if (wide_groups<T>(C, {ldda, ldy, lddy, dres ? lddres : 0}, {da, y, dy, dres}))
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<T, 8>), dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, da, ldda,
+                           y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
+    else
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<T, 4>), dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,
+                           y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
     YH_CHECK_LAUNCH("bn_silu_bwd_apply");
     return 0;
 }
