@@ -58,7 +58,12 @@ __device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
 
 __device__ __forceinline__ int mfma_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
 
-template <int BM, int BN, int WM, int WN, int NCLS>
+// C64: every class has Cin % 64 == 0, i.e. a 64-wide K chunk never straddles two taps.  The chunk's tap, its pixel
+// displacement and its weight rows are then the same for the whole workgroup (scalar work), and what is left per load is a
+// bounds test and an add.  The counters say why this matters: at bf16 MFMA rates a chunk's 16 MFMAs take ~500 cycles per wave
+// and the generic loader's ~130 vector instructions per chunk take longer than that (SQ_ACTIVE_INST_VALU 0.2-0.3 of every
+// wave's cycles at three waves per SIMD): the kernel was issue-bound on address arithmetic, not on memory or MFMA.
+template <int BM, int BN, int WM, int WN, int NCLS, int C64>
 __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     const BfGemm &g = gs.c[NCLS == 1 ? 0 : blockIdx.y];
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -111,7 +116,34 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     // two register sets: the loads of chunks c+1 and c+2 are both in flight while chunk c is multiplied (the layers are
     // latency-bound at bf16 MFMA rates: a chunk's 16 MFMAs take ~0.25 us, a global load ~1-2 us)
     u32x4 raA[AROWS], rbA[BPASS], raB[AROWS], rbB[BPASS];
+    // C64: per-thread constants of the B tile (which octet row / column each of the thread's pieces is)
+    int bo[BPASS], bnn[BPASS];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) {
+        const int e = t + 256 * p;
+        bo[p] = e / BN;
+        bnn[p] = n0 + (e - bo[p] * BN);
+        if (bo[p] >= 8 || bnn[p] >= g.ldw) bo[p] = 1 << 20;         // never valid
+    }
     auto load_tiles = [&](int c, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS]) {
+        if (C64) {
+            const int k0 = c * BK;                                   // workgroup-uniform from here on
+            const int tap = (int)__umulhi((unsigned)k0, g.cin_magic), ci0 = k0 - tap * g.Cin;
+            const int dy = tapt[tap], dx = tapt[9 + tap];
+            const int toff = (dy * g.Wi + dx) * g.ldi + ci0 + 8 * kq;
+            const bf16 *inb = (g.in2 && k0 >= g.ksplit) ? g.in2 - g.ksplit : g.in;
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                ra[i] = ok ? *(const u32x4 *)(inb + (roff[i] + toff)) : u32x4{0u, 0u, 0u, 0u};
+            }
+            const bf16 *wrow = g.w + ((size_t)(tapt[18 + tap] * cin8 + (ci0 >> 3)) * g.ldw << 3);
+            const int orem = (g.Ktot - k0) >> 3;                     // octet rows left in K (>= 8 except in a ragged last chunk)
+#pragma unroll
+            for (int p = 0; p < BPASS; ++p)
+                rb[p] = bo[p] < orem ? *(const u32x4 *)(wrow + ((size_t)(bo[p] * g.ldw + bnn[p]) << 3)) : u32x4{0u, 0u, 0u, 0u};
+            return;
+        }
         const int k = c * BK + 8 * kq;
         if (k < g.Ktot) {
             int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
@@ -318,13 +350,23 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
 
 constexpr int GEMM_BM = 128;
 
+template <int BN, int WM, int WN, int NCLS, int C64>
+int launch_cfg2(BfGemmSet &gs, hipStream_t st);
+
 template <int BN, int WM, int WN, int NCLS>
 int launch_cfg(BfGemmSet &gs, hipStream_t st) {
+    bool c64 = true;
+    for (int c = 0; c < NCLS; ++c) c64 = c64 && gs.c[c].Cin % 64 == 0 && (!gs.c[c].in2 || gs.c[c].ksplit % 64 == 0);
+    return c64 ? launch_cfg2<BN, WM, WN, NCLS, 1>(gs, st) : launch_cfg2<BN, WM, WN, NCLS, 0>(gs, st);
+}
+
+template <int BN, int WM, int WN, int NCLS, int C64>
+int launch_cfg2(BfGemmSet &gs, hipStream_t st) {
     constexpr int BM = GEMM_BM;
     constexpr size_t main_b = (size_t)2 * BM * A_STRIDE + 2 * 8 * BN * 16 + 27 * sizeof(int);
     constexpr size_t epi_b = (size_t)BM * (BN * 2 + 16) + (size_t)WM * BN * 2 * sizeof(float);
     constexpr size_t smem = main_b > epi_b ? main_b : epi_b;
-    auto kern = bf16_gemm_kernel<BM, BN, WM, WN, NCLS>;
+    auto kern = bf16_gemm_kernel<BM, BN, WM, WN, NCLS, C64>;
     if (int rc = yh_ensure_dyn_smem((const void *)kern, smem)) return rc;
     int maxblk = 0;
     for (int c = 0; c < NCLS; ++c) {
