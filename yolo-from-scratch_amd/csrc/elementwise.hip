@@ -5,6 +5,7 @@
 // are bitwise reproducible run to run.
 #include "common.h"
 #include <initializer_list>
+#include <stdlib.h>
 
 namespace {
 
@@ -544,8 +545,9 @@ __global__ void add_int64_kernel(int64_t *p, int64_t v) {
 }
 
 inline int grid_for(int64_t work_items, int threads = 256) {
+    static const int cap = getenv("YH_EW_MAXBLOCKS") ? atoi(getenv("YH_EW_MAXBLOCKS")) : kMaxBlocks;    // tuning knob
     int64_t g = cdiv64(work_items, threads);
-    return (int)(g < 1 ? 1 : (g > kMaxBlocks ? kMaxBlocks : g));
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 }  // namespace
