@@ -437,3 +437,48 @@ def test_narrow_direct_conv_kernel(B, H, W, Cin, Cout, s):
         assert rel_err(dxbuf[..., 4:].permute(0, 3, 1, 2), want) < 1e-5 and bool((dxbuf[..., :4] == 3.0).all())
         L.check(lib.yh_conv_narrow_dgrad_s2(dyg.data_ptr(), Cout, wb.data_ptr(), ldwb, dxv.data_ptr(), Cin + 4, B, H, W, Cin, Cout, 1, st), "dgrad s2 acc")
         assert rel_err(dxbuf[..., 4:].permute(0, 3, 1, 2), 2 * want) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,creal,Cout,s", [(2, 24, 64, 16, 16, 16, 1), (3, 23, 45, 16, 16, 16, 1), (2, 32, 96, 16, 16, 32, 2),
+                                                   (2, 21, 67, 16, 16, 32, 2), (2, 64, 96, 4, 3, 16, 2), (3, 37, 51, 4, 3, 16, 2),
+                                                   (16, 128, 160, 16, 16, 16, 1), (8, 256, 320, 4, 3, 16, 2)])
+def test_narrow_weight_gradient_kernel(B, H, W, Cin, creal, Cout, s):
+    """yh_conv_narrow_bwd_weight (pixels as the MFMA k dimension, persistent workgroups, fixed-order slab sum) = fp64 torch
+    weight gradient for the three narrow layer shapes: strided views of wider buffers, ragged patches, more patches than
+    workgroups (last case), bitwise reproducible, and equal to the generic yh_conv_bwd_weight to rounding."""
+    L = _lib()
+    lib = L.lib()
+    assert lib.yh_conv_narrow_bwd_weight_ok(Cin, creal, Cout, 3, s) == 1 and lib.yh_conv_narrow_bwd_weight_ok(32, 32, 32, 3, 1) == 0
+    torch.manual_seed(H * W + s)
+    x = torch.randn(B, creal, H, W)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    dy = torch.randn(B, Cout, Ho, Wo)
+    xd = x.double().requires_grad_(False)
+    w = torch.zeros(Cout, creal, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, w, None, s, 1).backward(dy.double())
+    want = w.grad
+    st = torch.cuda.current_stream().cuda_stream
+    ldx = Cin + 4
+    xbuf = torch.full((B, H, W, ldx), 9.0, device="cuda")
+    xbuf[..., 4:] = 0.0
+    xbuf[..., 4:4 + creal] = nhwc(x)
+    xv = xbuf.view(-1)[4:]
+    lddy = Cout + 8
+    dbuf = torch.full((B, Ho, Wo, lddy), 5.0, device="cuda")
+    dbuf[..., 4:4 + Cout] = nhwc(dy)
+    dv = dbuf.view(-1)[4:]
+    nws = lib.yh_conv_narrow_bwd_weight_ws(B, H, W, Cin, Cout, s)
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    dw = torch.full((Cout, creal, 3, 3), 7.0, device="cuda")
+    args = (xv.data_ptr(), ldx, dv.data_ptr(), lddy)
+    L.check(lib.yh_conv_narrow_bwd_weight(*args, dw.data_ptr(), ws.data_ptr(), nws, B, H, W, Cin, creal, Cout, s, st), "narrow wgrad")
+    assert rel_err(dw, want) < 1e-5
+    dw2 = torch.empty_like(dw)
+    L.check(lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), ws.data_ptr(), nws, B, H, W, Cin, creal, Cout, s, st), "narrow wgrad")
+    assert torch.equal(dw, dw2)
+    nws_g = lib.yh_conv_bwd_weight_ws(B, H, W, Cin, Cout, 3, s)
+    ws_g = torch.empty(nws_g, device="cuda")
+    dw3 = torch.empty_like(dw)
+    L.check(lib.yh_conv_bwd_weight(*args, dw3.data_ptr(), ws_g.data_ptr(), nws_g, B, H, W, Cin, creal, Cout, 3, s, st), "generic wgrad")
+    assert rel_err(dw, dw3) < 1e-5
+    assert lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), ws.data_ptr(), nws - 1, B, H, W, Cin, creal, Cout, s, st) != 0

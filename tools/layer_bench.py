@@ -60,7 +60,8 @@ def main():
                            L.OP_CONV_NARROW})
     DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA, L.OP_CONV_BWD_DATA_S2M,
           L.OP_BF16_CONV_BWD_DATA, L.OP_CONV_NARROW, L.OP_CONV_NARROW_DGRAD_S2}
-    tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT, L.OP_BF16_CONV_BWD_WEIGHT})
+    tb = time_ops(ba, bn, DG | {L.OP_CONV_BWD_WEIGHT, L.OP_CONV_WINO_BWD_WEIGHT, L.OP_CONV_PW_BWD_WEIGHT, L.OP_BF16_CONV_BWD_WEIGHT,
+                            L.OP_CONV_NARROW_BWD_WEIGHT})
     other_f = time_ops(fa, fn, {L.OP_BN_SILU_FWD, L.OP_BN_FINALIZE, L.OP_PACK_WEIGHTS, L.OP_MAXPOOL5_FWD, L.OP_BF16_BN_SILU_FWD,
                                 L.OP_BF16_MAXPOOL5_FWD, L.OP_BF16_PACK_MULTI})
     other_b = time_ops(ba, bn, {L.OP_BN_SILU_BWD_REDUCE, L.OP_BN_SILU_BWD_APPLY, L.OP_COLSUM, L.OP_MAXPOOL5_BWD,

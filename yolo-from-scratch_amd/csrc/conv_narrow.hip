@@ -11,6 +11,7 @@
 //   * epilogue: bias, optional accumulate, 64-byte row stores, per-workgroup BatchNorm partial sums (fixed order).
 // The same kernel computes backward-data of a stride-1 layer (flipped taps, the backward weight pack).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -221,6 +222,232 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
     }
 }
 
+// Backward-weight of the narrow layers (16 -> 16 stride 1 at 160x160, stem[3] 16 -> 32 stride 2, stem[0] 3(4) -> 16 stride 2):
+//     dW[tap][ci][co] = sum over output pixels p of x[p * S + tap - 1][ci] * dY[p][co]
+// The reduction runs over PIXELS, so one v_mfma_f32_16x16x4_f32 takes 4 consecutive output pixels of a row as its k:
+// A (rows) = the 16 input channels of one tap (CIN = 16) or 4 taps x 4 channels (CIN = 4), B (columns) = 16 output
+// channels.  With x staged [pixel][CIN] and dY staged [16-channel block][pixel][16], both fragments are ONE conflict-free
+// ds_read_b32 of 64 consecutive floats (stride 2 keeps even / odd input columns in two planes for that), and a dY fragment
+// serves all 9 taps.  A persistent workgroup walks patches of TH x TW output pixels (next patch's 16-byte global loads in
+// flight under the MFMAs of the current one), keeps the 9 (x COUT/16) accumulator tiles in registers the whole time and
+// writes one raw slab at the end; a fixed-order reduction turns the slabs into OIHW.  Every x and dY element is read once.
+struct NarrowW {
+    const float *x, *dy;
+    float *ws;
+    int ldx, lddy;
+    int B, Hi, Wi, Ho, Wo;
+    int tiles_x, tiles_y, npatch;
+};
+
+template <int CIN, int COUT, int S> struct NarrowWCfg {
+    static constexpr int TH = 8, TW = (S == 1 ? 32 : (CIN == 16 ? 16 : 32));
+    static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    static constexpr int PLANE = (IW + 1) / 2;                         // stride 2: pixels per parity plane of a row
+    static constexpr int ROWPX = S == 1 ? IW : 2 * PLANE;              // stored pixels per input row
+    static constexpr int QX = CIN / 4, QD = COUT / 4, NB = COUT / 16;
+    static constexpr int RG = CIN == 16 ? 9 : 3;                       // MFMA row groups (taps, or groups of 4 taps)
+    static constexpr int XPIECES = IH * IW * QX, DPIECES = TH * TW * QD;
+    static constexpr int NX = (XPIECES + 255) / 256, ND = (DPIECES + 255) / 256;
+    static constexpr int XS = IH * ROWPX * CIN, DS = TH * TW * COUT;   // floats
+    static constexpr int SLAB = RG * NB * 256;
+};
+
+template <int CIN, int COUT, int S>
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
+    typedef NarrowWCfg<CIN, COUT, S> C;
+    constexpr int TH = C::TH, TW = C::TW, IH = C::IH, IW = C::IW, PLANE = C::PLANE, ROWPX = C::ROWPX;
+    constexpr int QX = C::QX, QD = C::QD, NB = C::NB, RG = C::RG, NX = C::NX, ND = C::ND;
+    constexpr int GPR = TW / 4, NGRP = TH * GPR / 4;                   // 4-pixel groups per row / per wave
+    constexpr int RED = RG * NB * 4 * 64;                              // floats one wave parks for the cross-wave sum
+    constexpr int SMEM = (C::XS + C::DS) > 2 * RED ? (C::XS + C::DS) : 2 * RED;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float *xs = smem, *ds = smem + C::XS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, j = lane >> 4;
+
+    // per-thread staging plan, fixed for the whole kernel: piece k of this thread = 16 bytes (pixel (py, px) of the patch,
+    // channel quad q); gx/gd = its element offset from the patch origin in global memory, mx/md = LDS float offset | py << 16
+    // | px << 24 (py = 255 marks a slot past the end of the patch: its bounds check never passes)
+    int gx[NX], gd[ND];
+    unsigned mx[NX], md[ND];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = t + 256 * k;
+        const int q = i % QX, p = i / QX;
+        const int py = p / IW, px = p - py * IW;
+        const int sx = S == 1 ? px : (px & 1) * PLANE + (px >> 1);
+        gx[k] = (py * g.Wi + px) * g.ldx + 4 * q;
+        mx[k] = i < C::XPIECES ? (unsigned)((py * ROWPX + sx) * CIN + 4 * q) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int i = t + 256 * k;
+        const int q = i % QD, p = i / QD;                               // channels 4q..4q+3 of pixel p -> 16-channel block q / 4
+        const int py = p / TW, px = p - py * TW;
+        gd[k] = (py * g.Wo + px) * g.lddy + 4 * q;
+        md[k] = i < C::DPIECES ? (unsigned)(((q >> 2) * TH * TW + p) * 16 + 4 * (q & 3)) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
+    }
+    f32x4 rx[NX], rd[ND];
+    auto fetch = [&](int pid) {
+        const int tx = pid % g.tiles_x;
+        const int rest = pid / g.tiles_x;
+        const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        const float *xb = g.x + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldx;
+        const float *db = g.dy + ((ptrdiff_t)(b * g.Ho + oy0) * g.Wo + ox0) * g.lddy;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = *(const f32x4 *)(xb + gx[k]);
+            rx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int oy = oy0 + (int)((md[k] >> 16) & 255u), ox = ox0 + (int)(md[k] >> 24);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < g.Ho && ox < g.Wo) v = *(const f32x4 *)(db + gd[k]);
+            rd[k] = v;
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+            if (t + 256 * k < C::XPIECES) *(f32x4 *)(xs + (mx[k] & 0xffffu)) = rx[k];
+#pragma unroll
+        for (int k = 0; k < ND; ++k)
+            if (t + 256 * k < C::DPIECES) *(f32x4 *)(ds + (md[k] & 0xffffu)) = rd[k];
+    };
+
+    // per-lane LDS offsets (floats) of the A operand relative to the group's first pixel at tap (0, 0)
+    int aoff[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        int tap = CIN == 16 ? r : 4 * r + (col >> 2);
+        if (tap > 8) tap = 8;                                          // padding rows of the last 4-tap group: computed, never stored
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int pix = S == 1 ? ky * ROWPX + kx : ky * ROWPX + (kx & 1) * PLANE + (kx >> 1);
+        aoff[r] = (pix + j) * CIN + (CIN == 16 ? col : (col & 3));
+    }
+
+    f32x4 acc[RG][NB];
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int pid = blockIdx.x;
+    if (pid < g.npatch) fetch(pid);
+    for (; pid < g.npatch; pid += gridDim.x) {
+        __syncthreads();                                               // the previous patch's fragments are consumed
+        park();
+        __syncthreads();
+        if (pid + (int)gridDim.x < g.npatch) fetch(pid + gridDim.x);   // in flight under the MFMAs below
+#pragma unroll 2
+        for (int k = 0; k < NGRP; ++k) {
+            const int gi = wave + 4 * k;
+            const int row = gi / GPR, c0 = 4 * (gi - row * GPR);
+            const float *ap = xs + (size_t)((row * S) * ROWPX + c0) * CIN;
+            const float *bp = ds + (size_t)(row * TW + c0 + j) * 16 + col;
+            float bv[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) bv[n] = bp[n * TH * TW * 16];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const float a = ap[aoff[r]];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[n], acc[r][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- (w0 + w2) + (w1 + w3), fixed order, through LDS; wave 0 writes the raw slab ------------------------------------
+    __syncthreads();
+    float *red = smem;
+    auto put = [&](float *dst) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[((r * NB + n) * 4 + e) * 64 + lane] = acc[r][n][e];
+    };
+    auto add = [&](const float *src) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][n][e] += src[((r * NB + n) * 4 + e) * 64 + lane];
+    };
+    if (wave >= 2) put(red + (wave - 2) * RED);
+    __syncthreads();
+    if (wave < 2) add(red + wave * RED);
+    __syncthreads();
+    if (wave == 1) put(red);
+    __syncthreads();
+    if (wave == 0) {
+        add(red);
+        put(g.ws + (size_t)blockIdx.x * C::SLAB);
+    }
+}
+
+// dW (OIHW, cin_real input channels) = sum of the raw slabs in workgroup order.  16 outputs per workgroup, 16 partial
+// sums each (slab s, s + 16, ...), combined by a fixed tree.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int nslab,
+                                                                   int cin_real) {
+    constexpr int NB = COUT / 16, RG = CIN == 16 ? 9 : 3, SLAB = RG * NB * 256;
+    __shared__ float part[16][17];
+    const int t = threadIdx.x, e = blockIdx.x * 16 + (t & 15), s0 = t >> 4;
+    const int total = COUT * cin_real * 9;
+    float v = 0.f;
+    if (e < total) {
+        const int co = e / (cin_real * 9), rem = e - co * cin_real * 9;
+        const int ci = rem / 9, tap = rem - 9 * ci;
+        const int r = CIN == 16 ? tap : tap >> 2;
+        const int ln = (CIN == 16 ? (ci >> 2) : (tap & 3)) * 16 + (co & 15);
+        const int el = CIN == 16 ? (ci & 3) : ci;
+        const int idx = ((r * NB + (co >> 4)) * 4 + el) * 64 + ln;
+        for (int s = s0; s < nslab; s += 16) v += ws[(size_t)s * SLAB + idx];
+    }
+    part[t & 15][s0] = v;
+    __syncthreads();
+    if (t < 16 && blockIdx.x * 16 + t < total) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a += part[t][s];
+        dw[blockIdx.x * 16 + t] = a;
+    }
+}
+
+// persistent grid: measured best at 2 workgroups per CU for the 16-channel layers and 4 for the first layer (64 x 640 x 640:
+// 0.099 / 0.205 / 0.174 ms at 512 / 512 / 1024 workgroups; YH_NARROW_W_BLOCKS overrides for sweeps)
+int narrow_wgrad_grid(int npatch, int Cin) {
+    static const int forced = [] {
+        const char *e = getenv("YH_NARROW_W_BLOCKS");
+        return e ? atoi(e) : 0;
+    }();
+    const int target = forced > 0 ? forced : (Cin == 16 ? 512 : 1024);
+    return npatch < target ? npatch : target;
+}
+
+template <int CIN, int COUT, int S>
+int narrow_wgrad_launch(NarrowW g, float *dw, int cin_real, hipStream_t st) {
+    typedef NarrowWCfg<CIN, COUT, S> C;
+    g.tiles_x = cdiv(g.Wo, C::TW);
+    g.tiles_y = cdiv(g.Ho, C::TH);
+    g.npatch = g.B * g.tiles_x * g.tiles_y;
+    const int grid = narrow_wgrad_grid(g.npatch, CIN);
+    hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S>), dim3(grid), dim3(256), 0, st, g);
+    YH_CHECK_LAUNCH("conv_narrow_bwd_weight");
+    hipLaunchKernelGGL((narrow_wgrad_reduce_kernel<CIN, COUT>), dim3(cdiv(COUT * cin_real * 9, 16)), dim3(256), 0, st, g.ws, dw, grid,
+                       cin_real);
+    YH_CHECK_LAUNCH("conv_narrow_bwd_weight_reduce");
+    return 0;
+}
+
 int narrow_tiles(int Ho, int Wo, int s, int &tx, int &ty) {
     const int TH = s == 1 ? 8 : 4;
     tx = cdiv(Wo, 32);
@@ -276,4 +503,37 @@ extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, 
     else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2>), dim3(B * nt), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow");
     return 0;
+}
+
+extern "C" int yh_conv_narrow_bwd_weight_ok(int Cin, int cin_real, int Cout, int k, int s) {
+    if (k != 3) return 0;
+    if (Cin == 16 && cin_real == 16 && Cout == 16 && s == 1) return 1;
+    if (Cin == 16 && cin_real == 16 && Cout == 32 && s == 2) return 1;
+    if (Cin == 4 && cin_real >= 1 && cin_real <= 4 && Cout == 16 && s == 2) return 1;
+    return 0;
+}
+
+extern "C" int64_t yh_conv_narrow_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int s) {
+    const int Ho = (Hi - 1) / s + 1, Wo = (Wi - 1) / s + 1;
+    const int tw = s == 1 ? 32 : (Cin == 16 ? 16 : 32);
+    const int64_t npatch = (int64_t)B * cdiv(Wo, tw) * cdiv(Ho, 8);
+    const int64_t slab = (int64_t)(Cin == 16 ? 9 : 3) * (Cout / 16) * 256;
+    return (int64_t)narrow_wgrad_grid((int)(npatch < (1 << 30) ? npatch : (1 << 30)), Cin) * slab;
+}
+
+extern "C" int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                                         int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
+    YH_REQUIRE(x && dy && dw && ws && B > 0 && Hi > 0 && Wi > 0, "conv_narrow_bwd_weight: bad argument");
+    YH_REQUIRE(yh_conv_narrow_bwd_weight_ok(Cin, cin_real, Cout, 3, s), "conv_narrow_bwd_weight: unsupported shape %d(%d) -> %d stride %d",
+               Cin, cin_real, Cout, s);
+    YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && lddy >= Cout && lddy % 4 == 0 && ((uintptr_t)dy & 15) == 0,
+               "conv_narrow_bwd_weight: views must be 16-byte addressable");
+    YH_REQUIRE(ws_floats >= yh_conv_narrow_bwd_weight_ws(B, Hi, Wi, Cin, Cout, s), "conv_narrow_bwd_weight: workspace too small");
+    NarrowW g{};
+    g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy; g.B = B; g.Hi = Hi; g.Wi = Wi;
+    g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 16 && s == 1) return narrow_wgrad_launch<16, 16, 1>(g, dw, cin_real, st);
+    if (Cin == 16) return narrow_wgrad_launch<16, 32, 2>(g, dw, cin_real, st);
+    return narrow_wgrad_launch<4, 16, 2>(g, dw, cin_real, st);
 }

@@ -117,6 +117,7 @@ class ConvRec:
     s2m_b: bool = False     # stride-2 backward-data with the column parities merged into the channel axis
     narrow_f: bool = False  # forward on the direct kernel for the narrow high-resolution 3x3 layers
     narrow_b: bool = False  # stride-1 backward-data on the same kernel (flipped taps)
+    narrow_w: bool = False  # weight gradient on the direct pixel-reduction kernel
     fwd2: bool = False      # forward fused with the sibling pointwise conv (one GEMM, N = cout1 + cout2)
     nblk: int = 0           # BatchNorm partial-sum rows written by the forward kernel
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
@@ -371,6 +372,10 @@ class Plan:
                     r.wino_b = False
                 if nar_ok and r.s == 2 and r.need_dx and lib.yh_conv_narrow_dgrad_s2_ok(r.cin, r.cout):
                     r.narrow_b, r.s2m_b = True, False      # the stride-2 form of the direct backward-data kernel
+                r.narrow_w = bool(use_narrow and os.environ.get("YH_NARROW_W", "1") != "0" and r.k == 3 and r.x.ld % 4 == 0
+                                  and r.x.off % 4 == 0 and lib.yh_conv_narrow_bwd_weight_ok(r.cin, r.weight.shape[1], r.cout, 3, r.s))
+                if r.narrow_w:
+                    r.wino_w = False
                 if r.pair is None:
                     r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
                 elif r.pair_first:
@@ -679,7 +684,8 @@ class Plan:
         ws_floats = 1
         for r in self.recs:
             if isinstance(r, ConvRec):
-                ws_floats = max(ws_floats, lib.yh_conv_wino_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout) if r.wino_w else
+                ws_floats = max(ws_floats, lib.yh_conv_narrow_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.s) if r.narrow_w else
+                                lib.yh_conv_wino_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout) if r.wino_w else
                                 lib.yh_conv_pw_bwd_weight_ws(r.x.B * r.x.H * r.x.W, r.cin, r.cout) if r.pw_w else
                                 lib.yh_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
                 if r.bias is not None:
@@ -724,7 +730,8 @@ class Plan:
             if r.bias is not None:
                 ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
-            ops.append(_op(L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else (L.OP_CONV_PW_BWD_WEIGHT if r.pw_w else L.OP_CONV_BWD_WEIGHT),
+            ops.append(_op(L.OP_CONV_NARROW_BWD_WEIGHT if r.narrow_w else L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else
+                           (L.OP_CONV_PW_BWD_WEIGHT if r.pw_w else L.OP_CONV_BWD_WEIGHT),
                            p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
                            l=[self.ws.numel()]))
