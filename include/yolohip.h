@@ -137,7 +137,7 @@ int yh_conv_stem_blocks(int B, int Hi, int Wi);
  * (then x = dY, Cin / Cout = the convolution's Cout / Cin).  Same results and bn_partials contract as yh_conv_fwd
  * ([yh_conv_narrow_blocks(...)][2][Cout]).  replaces: train.py:300-306 (Bottleneck convs), 407 (stem[3]), 913. */
 int yh_conv_narrow_ok(int Cin, int Cout, int k, int s);
-int yh_conv_narrow_blocks(int B, int Hi, int Wi, int s);
+int yh_conv_narrow_blocks(int B, int Hi, int Wi, int Cin, int s);
 int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy, float *bn_partials, int B,
                    int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream);
 /* Input gradient of the stride-2 narrow layer (stem[3], Cin = 16, Cout = 32) as a direct kernel: one MFMA tile = 16 dX pixels

@@ -301,6 +301,18 @@ def test_stem_conv_direct_kernel(B, H, W):
     y2 = torch.empty(B, Ho, Wo, 16, device="cuda")
     L.check(lib.yh_conv_stem_fwd(x4.data_ptr(), wf.data_ptr(), None, y2.data_ptr(), 16, None, B, H, W, st))
     assert rel_err(y2.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, 2, 1)) < 1e-5
+    # the same layer on the direct MFMA kernel (CIN = 4 padded channels): output, untouched padding columns, partial sums
+    assert lib.yh_conv_narrow_ok(4, 16, 3, 2) == 1
+    y3 = torch.full((B, Ho, Wo, ldy), -1.0, device="cuda")
+    nb3 = lib.yh_conv_narrow_blocks(B, H, W, 4, 2)
+    part3 = torch.zeros(nb3, 2, 16, device="cuda")
+    L.check(lib.yh_conv_narrow(x4.data_ptr(), 4, wf.data_ptr(), 16, bias.cuda().data_ptr(), y3.data_ptr(), ldy, part3.data_ptr(),
+                               B, H, W, 4, 16, 2, 0, 0, st), "narrow first layer")
+    assert rel_err(y3[..., :16].permute(0, 3, 1, 2), ref) < 1e-5
+    assert float(y3[..., 16:].min()) == -1.0 == float(y3[..., 16:].max())
+    s3 = part3.double().sum(0).cpu()
+    assert float((s3[0] - od.sum((0, 2, 3))).abs().max() / od.sum((0, 2, 3)).abs().max()) < 1e-5
+    assert float((s3[1] - (od * od).sum((0, 2, 3))).abs().max() / (od * od).sum((0, 2, 3)).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 16, 32), (1, 17, 22, 16, 32), (2, 10, 12, 8, 24), (1, 8, 8, 32, 64)])
@@ -406,7 +418,7 @@ def test_narrow_direct_conv_kernel(B, H, W, Cin, Cout, s):
     ldy = Cout + 8
     ybuf = torch.full((B, Ho, Wo, ldy), 7.0, device="cuda")
     yv = ybuf.view(-1)[4:]
-    nblk = lib.yh_conv_narrow_blocks(B, H, W, s)
+    nblk = lib.yh_conv_narrow_blocks(B, H, W, Cin, s)
     part = torch.zeros(nblk * 2 * Cout, device="cuda")
     L.check(lib.yh_conv_narrow(xv.data_ptr(), ldx, wf.data_ptr(), ldwf, bias.cuda().data_ptr(), yv.data_ptr(), ldy, part.data_ptr(),
                                B, H, W, Cin, Cout, s, 0, 0, st), "narrow fwd")

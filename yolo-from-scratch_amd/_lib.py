@@ -69,7 +69,7 @@ _SIGS = {
     "yh_conv_stem_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
     "yh_conv_stem_blocks": (i32, [i32, i32, i32]),
     "yh_conv_narrow_ok": (i32, [i32, i32, i32, i32]),
-    "yh_conv_narrow_blocks": (i32, [i32, i32, i32, i32]),
+    "yh_conv_narrow_blocks": (i32, [i32, i32, i32, i32, i32]),
     "yh_conv_narrow_dgrad_s2_ok": (i32, [i32, i32]),
     "yh_conv_narrow_bwd_weight_ok": (i32, [i32, i32, i32, i32, i32]),
     "yh_conv_narrow_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32]),

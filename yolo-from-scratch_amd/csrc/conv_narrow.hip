@@ -26,7 +26,7 @@ struct Narrow {
 
 template <int CIN, int COUT, int S>
 __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
-    constexpr int TW = 32, TH = S == 1 ? 8 : 4;          // output patch
+    constexpr int TW = 32, TH = (S == 1 || CIN == 4) ? 8 : 4;   // output patch
     constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;
     constexpr int Q = CIN / 4, NT = COUT / 16;
     constexpr int MT = TH * 2 / 4;                        // 16-pixel row segments per wave (TH rows x 2 halves over 4 waves)
@@ -448,8 +448,8 @@ int narrow_wgrad_launch(NarrowW g, float *dw, int cin_real, hipStream_t st) {
     return 0;
 }
 
-int narrow_tiles(int Ho, int Wo, int s, int &tx, int &ty) {
-    const int TH = s == 1 ? 8 : 4;
+int narrow_tiles(int Ho, int Wo, int Cin, int s, int &tx, int &ty) {
+    const int TH = (s == 1 || Cin == 4) ? 8 : 4;
     tx = cdiv(Wo, 32);
     ty = cdiv(Ho, TH);
     return tx * ty;
@@ -458,13 +458,13 @@ int narrow_tiles(int Ho, int Wo, int s, int &tx, int &ty) {
 }  // namespace
 
 extern "C" int yh_conv_narrow_ok(int Cin, int Cout, int k, int s) {
-    return k == 3 && ((Cin == 16 && Cout == 16 && s == 1) || (Cin == 16 && Cout == 32 && s == 2)) ? 1 : 0;
+    return k == 3 && ((Cin == 16 && Cout == 16 && s == 1) || (Cin == 16 && Cout == 32 && s == 2) || (Cin == 4 && Cout == 16 && s == 2)) ? 1 : 0;
 }
 
-extern "C" int yh_conv_narrow_blocks(int B, int Hi, int Wi, int s) {
+extern "C" int yh_conv_narrow_blocks(int B, int Hi, int Wi, int Cin, int s) {
     const int Ho = (Hi - 1) / s + 1, Wo = (Wi - 1) / s + 1;
     int tx, ty;
-    return B * narrow_tiles(Ho, Wo, s, tx, ty);
+    return B * narrow_tiles(Ho, Wo, Cin, s, tx, ty);
 }
 
 extern "C" int yh_conv_narrow_dgrad_s2_ok(int Cin, int Cout) { return Cin == 16 && Cout == 32 ? 1 : 0; }
@@ -497,9 +497,10 @@ extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, 
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.B = B; g.Hi = Hi; g.Wi = Wi;
     g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
     g.flip = flip_taps ? 1 : 0; g.accumulate = accumulate ? 1 : 0;
-    const int nt = narrow_tiles(g.Ho, g.Wo, s, g.tiles_x, g.tiles_y);
+    const int nt = narrow_tiles(g.Ho, g.Wo, Cin, s, g.tiles_x, g.tiles_y);
     hipStream_t st = (hipStream_t)stream;
     if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1>), dim3(B * nt), dim3(256), 0, st, g);
+    else if (Cin == 4) hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2>), dim3(B * nt), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2>), dim3(B * nt), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow");
     return 0;

@@ -365,6 +365,8 @@ class Plan:
                 # narrow high-resolution 3x3 layers: direct kernel (LDS halo patch, filter in registers, 16-wide MFMA tiles)
                 nar_ok = use_narrow and r.k == 3 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and r.x.off % 4 == 0
                 r.narrow_f = bool(nar_ok and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s))
+                if r.stem_f and use_narrow and os.environ.get("YH_NARROW_STEM", "1") != "0" and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s):
+                    r.narrow_f, r.stem_f = True, False    # first layer: the same direct MFMA kernel with CIN = 4 (padded) channels
                 r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
                 if r.narrow_f:
                     r.wino_f = False
@@ -442,7 +444,7 @@ class Plan:
                         elif ln == 1 or q.lane == 1:
                             raise NotImplementedError("fused sibling convolution traced on the side lane without a preceding fork")
                 else:
-                    nblk = lib.yh_conv_narrow_blocks(r.x.B, r.x.H, r.x.W, r.s) if r.narrow_f else \
+                    nblk = lib.yh_conv_narrow_blocks(r.x.B, r.x.H, r.x.W, r.cin, r.s) if r.narrow_f else \
                         lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
                         lib.yh_conv_pw_blocks(M, r.cin, r.cout) if r.pw_f else \
                         lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
