@@ -216,6 +216,7 @@ int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const floa
 int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw, const float *bias1, float *y1, int ldy1,
                     float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2, int cout2,
                     int64_t M, int Cin, void *stream);
+int yh_conv_pw_bwd_data_bn_rows(int64_t M, int K, int Cin);   /* rows of the partial sums yh_conv_pw_bwd_data_bn writes */
 int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw, float *dx,
                         int lddx, int64_t M, int Cin, int accumulate, void *stream);
 /* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction

@@ -78,6 +78,7 @@ _SIGS = {
     "yh_conv_narrow": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pw_pack_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_pw_blocks": (i32, [i64, i32, i32]),
+    "yh_conv_pw_bwd_data_bn_rows": (i32, [i64, i32, i32]),
     "yh_conv_pw_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i64, i32, i32, c_fp]),
     "yh_conv_pw_fwd2": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, c_fp]),
     "yh_conv_pw_bwd_data": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i64, i32, i32, c_fp]),

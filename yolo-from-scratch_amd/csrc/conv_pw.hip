@@ -9,6 +9,11 @@
 // XV*DV MFMAs.  The four waves of a workgroup walk disjoint pixel ranges of the same (ci, co) tile and are summed
 // through LDS; workgroups write [Cin][Cout] slabs that a fixed-order reduction adds up (bitwise reproducible).
 #include "common.h"
+#include <stdlib.h>
+#ifdef YH_PW_STAMPS
+#include <stdio.h>
+#include <vector>
+#endif
 
 namespace {
 
@@ -243,6 +248,9 @@ struct PwG {
     const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns (common.h)
     int bn_n;
     const float *res;           // inference epilogue (tiled kernel only): SiLU on (acc + bias), + residual, x2 upsample on write
+#ifdef YH_PW_STAMPS
+    unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps (tools/pw_probe.py)
+#endif
     int ldr, act, up2, H, W;    // H, W: image size (up2 needs the pixel's row / column)
 };
 
@@ -394,6 +402,227 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
     }
 }
 
+// The same GEMM with the A operand staged through LDS (training-path layers with K >= 64 that do not stream).  PMC on the
+// register-direct kernel above (128 -> 128 at 40x40, 75 us = 45 TFLOP/s): waves sit in s_waitcnt 57 % of their cycles, the L1
+// is stalled on pending fills, and L2 -> L1 traffic is 3.5x the operands -- a lane's 16-byte A loads touch 32 different
+// cache lines per instruction and every wave streams the full weight panel by itself.  Here a workgroup owns 128 pixels x
+// (32 WN) channels: the A chunk (128 pixels x up to 128 channels) is read ONCE with row-contiguous 16-byte loads (next chunk
+// prefetched into registers under the MFMAs) and parked in LDS with a 132-float row stride (conflict-free ds_read_b128 of a
+// lane's four consecutive k); wave (wm, wn) multiplies TMW x 32 rows by ITS OWN 32 columns, so each weight fragment is
+// fetched by exactly one wave of the workgroup.  Same operand maps, k order per 8-channel group, epilogue and partial-sum
+// contract as pw_gemm_kernel.
+template <int TMW, int WN>
+__global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
+    constexpr int WM = 4 / WN, BM = 32 * TMW * WM, KC = 128, LDA = KC + 4, NP = BM * (KC / 4) / 256;
+    extern __shared__ __attribute__((aligned(16))) float pw_as[];     // [BM][LDA]; reused for the partial-sum exchange
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int n = (blockIdx.y * WN + wn) * 32 + lr;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g.in, 0, g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void *)(g.in2 ? g.in2 : g.in), 0, g.in2 ? g.in2_bytes : 0u, 0x00020000);
+    const int nch1 = (g.K1 + KC - 1) / KC, nch = nch1 + (g.K - g.K1 + KC - 1) / KC;
+    const int ntiles = (g.M + BM - 1) / BM;
+
+    // staging plan: piece j of this thread = 16 bytes of row (t >> 5) + 8 j, channels 4 (t & 31) .. + 3 of the chunk
+    const int col4 = t & 31, row0 = t >> 5;
+    f32x4 rx[NP];
+    // quarter q (0..3) of the loads of chunk ci of `tile`: issued a quarter at a time between the MFMA groups of the
+    // previous chunk, so that the weight fragments those groups wait for are never queued behind a burst of A loads
+    // (vmcnt retires in order)
+    auto fetch_q = [&](int tile, int ci, int q) {
+        const bool second = ci >= nch1;
+        const int kb = (second ? ci - nch1 : ci) * KC;
+        const int kc = (second ? g.K - g.K1 : g.K1) - kb;                   // channels left in this tensor (>= 1)
+        const unsigned dead = (unsigned)(4 * col4 >= kc) << 31;
+        const int p0 = tile * BM + row0;
+        const unsigned base = ((unsigned)p0 * (unsigned)g.ldi + 4u * col4 + (unsigned)kb) * 4u, rstep = 8u * (unsigned)g.ldi * 4u;
+#pragma unroll
+        for (int jj = 0; jj < NP / 4; ++jj) {
+            const int j = q * (NP / 4) + jj;
+            const unsigned off = (base + (unsigned)j * rstep) | dead | ((unsigned)(p0 + 8 * j >= g.M) << 31);
+            rx[j] = second ? buf_load<4>(r2, off) : buf_load<4>(r1, off);
+        }
+    };
+    auto fetch = [&](int tile, int ci) {
+        fetch_q(tile, ci, 0); fetch_q(tile, ci, 1); fetch_q(tile, ci, 2); fetch_q(tile, ci, 3);
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) *(f32x4 *)(pw_as + (row0 + 8 * j) * LDA + 4 * col4) = rx[j];
+    };
+
+    const float *wbase = g.Wq + ((size_t)lh * g.ldw + (n < g.ldw ? n : 0)) * 4;      // columns past N are never stored
+    const size_t wstep = (size_t)2 * g.ldw * 4;                                        // one 8-channel group of weight rows
+    const float *abase = pw_as + (wm * TMW * 32 + lr) * LDA + 4 * lh;
+
+    // per-column epilogue state
+    const bool nok = n < g.N, second = n >= g.N1;
+    const int nl = second ? n - g.N1 : n;
+    const float *bp = second ? g.bias2 : g.bias;
+    const float bias = (bp && nok) ? bp[nl] : 0.f;
+    float *const ob = (second ? g.out2 : g.out) + nl;
+    const int ldo = second ? g.ldo2 : g.ldo;
+    const int nb0 = (blockIdx.y * WN + wn) * 32;                            // this wave's first column
+    const bool cols_whole = nb0 + 32 <= g.N && (nb0 >= g.N1 || nb0 + 32 <= g.N1);          // wave-uniform
+    const bool sec_u = nb0 >= g.N1;                                          // scalar copies of the per-lane selections
+    const int ldo_u = sec_u ? g.ldo2 : g.ldo;
+    float *const ob_u = sec_u ? g.out2 : g.out;
+
+    // weight fragments: a ring of PD groups (8 channels each) kept PD groups ahead of the MFMAs, running on across A chunks
+    // and (wrapping to group 0) across tiles; vmcnt retires in order, so the ring is filled BEFORE the A loads are issued
+    constexpr int PD = 4;
+    const int G = g.K >> 3;                                                 // K % 32 == 0 here (launcher)
+    f32x4 bq[PD];
+#pragma unroll
+    for (int u = 0; u < PD; ++u) bq[u] = *(const f32x4 *)(wbase + (size_t)u * wstep);
+
+    // A persistent workgroup walks pixel tiles blockIdx.x, + gridDim.x, ...: the first A chunk of the NEXT tile is already in
+    // flight while the last chunk of the current one is multiplied and while its epilogue stores drain, so load, MFMA and
+    // store phases of the chip overlap instead of alternating (one tile per workgroup ran 7.5 + 13.6 + 7 us per round of
+    // 512 workgroups on 128 -> 128 at 160x160: every workgroup loading, then multiplying, then storing at the same time).
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+#ifdef YH_PW_STAMPS
+        const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long st1 = 0, st2 = 0;
+#endif
+        const int m0 = tile * BM;
+        f32x16 acc[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int gs = 0;                                                         // first weight group of the current chunk
+        for (int ci = 0; ci < nch; ++ci) {
+            const bool seg2 = ci >= nch1;
+            const int kb = (seg2 ? ci - nch1 : ci) * KC;
+            int kc = (seg2 ? g.K - g.K1 : g.K1) - kb;
+            if (kc > KC) kc = KC;
+            __syncthreads();                                                // the previous chunk's fragments / sums are consumed
+            park();
+            __syncthreads();
+#ifdef YH_PW_STAMPS
+            if (ci == 0) st1 = __builtin_amdgcn_s_memtime();
+#endif
+            // the next chunk (of this tile, or the first one of the next tile) is fetched under the MFMAs below
+            const bool more = ci + 1 < nch || tile + (int)gridDim.x < ntiles;
+            const int nt_tile = ci + 1 < nch ? tile : tile + (int)gridDim.x, nt_ci = ci + 1 < nch ? ci + 1 : 0;
+            const int ns = kc >> 3;
+            f32x4 a0[TMW], a1[TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) a0[i] = *(const f32x4 *)(abase + i * 32 * LDA);
+            // one group: take the weight fragment loaded PD groups ago, refill its ring slot, read the NEXT group's A
+            // fragments from LDS, then 4 TMW MFMAs -- everything issued ahead of the MFMAs that hide it
+            auto group = [&](int sc, int u, const f32x4 (&ac)[TMW], f32x4 (&an)[TMW]) {
+                const f32x4 b = bq[u];
+                int nx = gs + sc + PD;
+                if (nx >= G) nx -= G;
+                bq[u] = *(const f32x4 *)(wbase + (size_t)nx * wstep);
+                const int sn = sc + 1 < ns ? sc + 1 : sc;
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) an[i] = *(const f32x4 *)(abase + i * 32 * LDA + 8 * sn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][e], b[e], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // vmcnt retires in order: a weight fragment requested after a burst of A loads is not "there" before they are.
+            // Inside a tile the next chunk's A loads go out at once at the chunk's start (one possible stall per chunk, PD
+            // groups later); the next TILE's first chunk goes out after the last MFMA group, ahead of the epilogue, whose
+            // stores need no waiting -- stamps: loads spread between the groups cost 1.65x the MFMA time of the loop.
+            if (more && ci + 1 < nch) fetch(nt_tile, nt_ci);
+            for (int s8 = 0; s8 < ns; s8 += PD) {                           // ns % PD == 0: K segments are multiples of 32 here
+                group(s8 + 0, 0, a0, a1);
+                group(s8 + 1, 1, a1, a0);
+                group(s8 + 2, 2, a0, a1);
+                group(s8 + 3, 3, a1, a0);
+            }
+            if (more && ci + 1 == nch) fetch(nt_tile, nt_ci);
+            gs += ns;
+        }
+
+#ifdef YH_PW_STAMPS
+        st2 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- epilogue: bias / accumulate, 128-byte row stores, per-tile column sums ------------------------------------
+        float cs = 0.f, cq = 0.f;
+        if (cols_whole && m0 + BM <= g.M) {
+            // full tile, all 32 columns in one tensor: no per-element tests; row offsets are compile-time multiples of ldo
+            float *const o0 = ob_u + (size_t)(m0 + wm * TMW * 32) * ldo_u + ((size_t)(4 * lh) * ldo_u + nl);
+            if (!g.accumulate) {
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][r] + bias;
+                        o0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo_u] = v;
+                        cs += v;
+                        cq += v * v;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = o0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo_u];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][r] + bias + old[r];
+                        o0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo_u] = v;
+                        cs += v;
+                        cq += v * v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = m0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (nok && p < g.M) {
+                        float *o = ob + (size_t)p * ldo;
+                        float v = acc[i][r] + bias;
+                        if (g.accumulate) v += *o;
+                        *o = v;
+                        cs += v;
+                        cq += v * v;
+                    }
+                }
+        }
+        if (g.stats) {
+            float(*red)[32][2] = (float(*)[32][2])pw_as;                    // [4 waves][32][2]
+            cs += __shfl_xor(cs, 32);
+            cq += __shfl_xor(cq, 32);
+            __syncthreads();                                                // all waves are done with the A tile
+            if (lh == 0) { red[wave][lr][0] = cs; red[wave][lr][1] = cq; }
+            __syncthreads();
+            if (t < 32 * WN) {
+                const int cw = t >> 5, cl = t & 31, nn = (blockIdx.y * WN + cw) * 32 + cl;
+                if (nn < g.N) {
+                    float a0s = 0.f, a1s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) { a0s += red[w * WN + cw][cl][0]; a1s += red[w * WN + cw][cl][1]; }
+                    float *sp = nn >= g.N1 ? g.stats2 : g.stats;              // each tensor has its own [tiles][2][C] partials
+                    const int C = nn >= g.N1 ? g.N - g.N1 : g.N1, nnl = nn >= g.N1 ? nn - g.N1 : nn;
+                    sp[((size_t)tile * 2 + 0) * C + nnl] = a0s;
+                    sp[((size_t)tile * 2 + 1) * C + nnl] = a1s;
+                }
+            }
+        }
+#ifdef YH_PW_STAMPS
+        if (g.dbg && t == 0 && blockIdx.y == 0) {
+            unsigned long long *d = g.dbg + (size_t)tile * 6;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+    }
+}
+
 // Small-K, small-N, many-pixel pointwise layers (the 160^2 / 80^2 1x1 convs: K <= 64, memory-bound): a STREAMING form of the
 // same GEMM.  All B fragments of the layer (K/8 x NT float4 per lane) are loaded once and stay in registers; a fixed grid of
 // workgroups walks the pixel groups (32 pixels per wave and trip), prefetching the next group's A operand while the
@@ -535,6 +764,27 @@ inline int pw_stream_blocks(int64_t M) {
     return (int)(b > 1024 ? 1024 : b);
 }
 
+// LDS-staged form: every tiled (non-streaming) training-path layer with K >= 64 (YH_PW_TILE=0 switches back to the
+// register-direct kernel for A/B runs)
+// pixels per workgroup of the LDS-staged form: 64 (more, smaller workgroups: 3-4 per CU instead of 2) unless N <= 32
+inline int pw_tile_bm(int N) {
+    static const int forced = getenv("YH_PW_BM") ? atoi(getenv("YH_PW_BM")) : 0;
+    if (N <= 32) return 128;
+    if (forced == 64 || forced == 128) return forced;
+    return N <= 64 ? 64 : 128;                 // measured: 64 wins for N = 64 (33 vs 40 us at 128 -> 64, 40x40), 128 for N >= 128
+}
+inline int pw_tile_slots(int BM) {
+    static const int forced = getenv("YH_PW_SLOTS") ? atoi(getenv("YH_PW_SLOTS")) : 0;
+    if (forced > 0) return forced;
+    (void)BM;
+    return 512;                                // 2 workgroups per CU (67 KB of LDS at 128 rows; ~200 VGPRs at 64)
+}
+inline bool pw_use_tile(int K, int N) {
+    static const bool on = !(getenv("YH_PW_TILE") && atoi(getenv("YH_PW_TILE")) == 0);
+    (void)N;
+    return on && K >= 64 && K % 32 == 0;
+}
+
 struct PwPackDesc {
     const float *w;             // [Cout][Cin] (OIHW, 1x1)
     float *wf, *wb;             // forward: Wq[Cin/4][ldwf][4]; backward-data: Wq[(koff + Cout)/4 rows...][ldwb][4]
@@ -581,9 +831,62 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
         YH_CHECK_LAUNCH("pw_stream");
         return 0;
     }
-    const int TM = (NT <= 2 && cdiv(g.M, 256) * cdiv(g.N, 32 * NT) >= 1024) ? 2 : 1;   // <2,4> would run one wave per SIMD
-    dim3 grid(cdiv(g.M, 128 * TM), cdiv(g.N, 32 * NT));
+    if (!fused && !g.bn_n && g.K1 % 32 == 0 && (g.K - g.K1) % 32 == 0 && pw_use_tile(g.K, g.N)) {
+        const int WN = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
+        const int BM = pw_tile_bm(g.N);
+        const int ntile = cdiv(g.M, BM), ncol = cdiv(g.N, 32 * WN);
+        const int slots = pw_tile_slots(BM);                                 // resident workgroups on the chip
+        int gx = cdiv(slots, ncol);
+        if (gx > ntile) gx = ntile;
+        gx = cdiv(ntile, cdiv(ntile, gx));                                   // same number of rounds, evenly filled
+        dim3 tg(gx, ncol);
+#ifdef YH_PW_STAMPS
+        static unsigned long long *dbgbuf = nullptr;
+        if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
+        g.dbg = getenv("YH_PW_DBG") && (size_t)ntile * 48 <= ((size_t)1 << 24) ? dbgbuf : nullptr;
+#endif
+        const size_t smem = (size_t)BM * 132 * sizeof(float);
+        int rc = 0;
+#define YH_PWT(tmw, wn)                                                                          \
+    do {                                                                                         \
+        rc = yh_ensure_dyn_smem((const void *)pw_tile_kernel<tmw, wn>, smem);                    \
+        if (!rc) hipLaunchKernelGGL((pw_tile_kernel<tmw, wn>), tg, dim3(256), smem, st, g);      \
+    } while (0)
+        if (WN == 4) { if (BM == 64) YH_PWT(2, 4); else YH_PWT(4, 4); }
+        else if (WN == 2) { if (BM == 64) YH_PWT(1, 2); else YH_PWT(2, 2); }
+        else YH_PWT(1, 1);
+#undef YH_PWT
+        if (rc) return rc;
+        YH_CHECK_LAUNCH("pw_tile");
+#ifdef YH_PW_STAMPS
+        if (getenv("YH_PW_DBG")) {
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> h((size_t)ntile * 6);
+            (void)hipMemcpy(h.data(), g.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            double a = 0, b = 0, c = 0, rt = 0; unsigned long long lo = ~0ull, hi = 0; int cnt = 0;
+            for (int i = gx; i < ntile; ++i) {       // tiles after each workgroup's first one (steady state)
+                a += (double)(h[6 * i + 1] - h[6 * i]); b += (double)(h[6 * i + 2] - h[6 * i + 1]); c += (double)(h[6 * i + 3] - h[6 * i + 2]);
+                rt += (double)(h[6 * i + 5] - h[6 * i + 4]); ++cnt;
+            }
+            for (int i = 0; i < ntile; ++i) { if (h[6 * i + 4] < lo) lo = h[6 * i + 4]; if (h[6 * i + 5] > hi) hi = h[6 * i + 5]; }
+            if (cnt) fprintf(stderr, "[pw stamps] tiles %d grid %d: park+barriers %.0f, multiply %.0f, epilogue %.0f ticks per tile = %.2f us (clock %.2f GHz); kernel span %.1f us\n",
+                             ntile, gx, a / cnt, b / cnt, c / cnt, rt / cnt / 100.0, (a + b + c) / rt * 0.1, (double)(hi - lo) / 100.0);
+        }
+#endif
+        return 0;
+    }
+    int NTv = NT;
+    int TM = (NT <= 2 && cdiv(g.M, 256) * cdiv(g.N, 32 * NT) >= 1024) ? 2 : 1;   // <2,4> would run one wave per SIMD
+    if (const char *e = getenv("YH_PW_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && 32 * v <= ((g.N + 31) & ~31)) NTv = v; }
+    if (const char *e = getenv("YH_PW_TM")) { const int v = atoi(e); if (v == 1 || v == 2) TM = v; }
+    dim3 grid(cdiv(g.M, 128 * TM), cdiv(g.N, 32 * NTv));
 #define YH_PWG(tm, nt) hipLaunchKernelGGL((pw_gemm_kernel<tm, nt>), grid, dim3(256), 0, st, g)
+    if (NTv != NT || getenv("YH_PW_TM")) {      // tuning probe (tools/pw_probe.py): explicit tile shape; partial-sum rows follow grid.x
+        if (TM == 2) { if (NTv == 4) YH_PWG(2, 4); else if (NTv == 2) YH_PWG(2, 2); else YH_PWG(2, 1); }
+        else { if (NTv == 4) YH_PWG(1, 4); else if (NTv == 2) YH_PWG(1, 2); else YH_PWG(1, 1); }
+        YH_CHECK_LAUNCH("pw_gemm");
+        return 0;
+    }
     if (TM == 2) { if (NT == 2) YH_PWG(2, 2); else YH_PWG(2, 1); }
     else { if (NT == 4) YH_PWG(1, 4); else if (NT == 2) YH_PWG(1, 2); else YH_PWG(1, 1); }
 #undef YH_PWG
@@ -593,8 +896,17 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
 
 }  // namespace
 
+// partial-sum rows of the backward-data kernels that carry a BatchNorm table (always the register-direct / streaming forms)
+extern "C" int yh_conv_pw_bwd_data_bn_rows(int64_t M, int K, int Cin) {
+    if (pw_use_stream(M, K, Cin)) return pw_stream_blocks(M);
+    const int NT = Cin > 64 ? 4 : (Cin > 32 ? 2 : 1);
+    const int TM = (NT <= 2 && cdiv((int)M, 256) * cdiv(Cin, 32 * NT) >= 1024) ? 2 : 1;
+    return cdiv((int)M, 128 * TM);
+}
+
 extern "C" int yh_conv_pw_blocks(int64_t M, int K, int Cout) {
     if (pw_use_stream(M, K, Cout)) return pw_stream_blocks(M);
+    if (pw_use_tile(K, Cout)) return cdiv((int)M, pw_tile_bm(Cout));
     const int NT = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
     const int TM = (NT <= 2 && cdiv((int)M, 256) * cdiv(Cout, 32 * NT) >= 1024) ? 2 : 1;
     return cdiv((int)M, 128 * TM);

@@ -802,7 +802,7 @@ class Plan:
                 continue
             M = w.B * w.H * w.W
             rows = lib.yh_conv_wino_blocks(w.B, w.H, w.W) if kind == L.OP_CONV_WINO_BWD_DATA else \
-                lib.yh_conv_pw_blocks(M, c.cout + (c.pair.cout if c.pair is not None else 0), w.C)
+                lib.yh_conv_pw_bwd_data_bn_rows(M, c.cout + (c.pair.cout if c.pair is not None else 0), w.C)
             part = torch.empty(rows * 2 * rec.cout, device=self.device, dtype=torch.float32)
             keep.append(part)
             tables[k].append((rec.y.data_ptr(), rec.coef.data_ptr(), part.data_ptr(), lo - w.off, rec.cout, rec.cout, rec.cout, 0, 0))
