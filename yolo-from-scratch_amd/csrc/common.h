@@ -10,6 +10,17 @@ void yh_set_error(const char *fmt, ...);
 // opt a kernel into `bytes` of dynamic LDS on the current device (api.hip: mutex-guarded (device, kernel) table)
 int yh_ensure_dyn_smem(const void *fn, size_t bytes);
 
+// Pointers that are SELECTED at run time (tensor A or tensor B, the input or a zero page, a table entry) lose their address
+// space and compile to FLAT loads / stores.  A flat access counts on vmcnt AND lgkmcnt and may retire out of order, so every
+// later wait becomes s_waitcnt vmcnt(0) lgkmcnt(0): a software prefetch issued before it is waited for in full (the Winograd
+// loop ran 1.8x its MFMA time that way).  Everything the kernels touch through such pointers is global memory: say so.
+#define YH_GLOBAL __attribute__((address_space(1)))
+typedef YH_GLOBAL float gfloat;
+template <typename T>
+__device__ __forceinline__ YH_GLOBAL T *yh_global(T *p) { return (YH_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ const YH_GLOBAL T *yh_global(const T *p) { return (const YH_GLOBAL T *)p; }
+
 #define YH_REQUIRE(cond, ...)                                  \
     do {                                                       \
         if (!(cond)) {                                         \

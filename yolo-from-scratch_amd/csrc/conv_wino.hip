@@ -20,6 +20,10 @@
 // The same kernel computes backward-data (correlation of dY with the flipped, transposed filter).
 // Numerics: fp32 throughout; F(2,3) transform constants are {0, +-1, +-1/2}, error growth is a few ulp.
 #include "common.h"
+#ifdef YH_WINO_STAMPS
+#include <stdio.h>
+#include <vector>
+#endif
 
 namespace {
 
@@ -40,6 +44,9 @@ struct Wino {
     int ldr, act, up2;          // act: SiLU on (acc + bias); up2: each output pixel replicated 2x2 (out is (B,2H,2W))
     unsigned tw_magic, tpi_magic;
     int tw_shift, tpi_shift;
+#ifdef YH_WINO_STAMPS
+    unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps
+#endif
 };
 
 constexpr int ZPAD = 2048;      // padding pixels read zeros from here (K <= ZPAD)
@@ -55,6 +62,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
     constexpr int BNW = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats)
 
+#ifdef YH_WINO_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): remap the linear id so that every
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
 
-    const float *dp[2][4];                     // per-lane pixel pointers; padding pixels point into wino_zeros
+    const gfloat *dp[2][4];                    // per-lane pixel pointers (global address space: see YH_GLOBAL); padding pixels point into wino_zeros
     {
         int tg = tile0 + lr;
         bool tv = tg < g.ntiles;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             for (int c = 0; c < 4; ++c) {
                 int ix = 2 * tx - 1 + c;
                 bool ok = tv && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                dp[rr][c] = (ok ? g.in + (size_t)((b * g.H + iy) * g.W + ix) * g.ldi : wino_zeros) + 4 * lh;
+                dp[rr][c] = (ok ? yh_global(g.in) + (size_t)((b * g.H + iy) * g.W + ix) * g.ldi : yh_global(&wino_zeros[0])) + 4 * lh;
             }
         }
     }
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) d[rr][cc] = *(const f32x4 *)(dp[rr][cc] + c * KC);
+            for (int cc = 0; cc < 4; ++cc) d[rr][cc] = *(const YH_GLOBAL f32x4 *)(dp[rr][cc] + c * KC);
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -142,6 +152,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
                     acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], u[v][j][e], acc[v][j], 0, 0, 0);
     };
     const int nchunks = g.K / KC;              // even (K % 16 == 0)
+#ifdef YH_WINO_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (PIPE == 2) {
         load_chunk(0, dA, uA);
         for (int c = 0; c < nchunks; c += 2) {
@@ -163,6 +176,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
         }
     }
 
+#ifdef YH_WINO_STAMPS
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- output transform.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
     float *S = smem;                           // [xi 4][j 2][tile 32][ch BNW]
 #pragma unroll
@@ -253,6 +269,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             }
         }
     }
+#ifdef YH_WINO_STAMPS
+    if (g.dbg && t == 0) {
+        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // U[pos][k/4][n][k%4] = (G g G^T)[pos] with g = w[n][k][.][.] (forward, k = ci, n = co) or the flipped filter of
@@ -534,8 +556,31 @@ int launch_nt(Wino &g, hipStream_t st) {
     g.ncol = cdiv(g.N, BNW);
     constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2) * sizeof(float);
     if (int rc = yh_ensure_dyn_smem((const void *)wino_kernel<NT, PIPE>, smem)) return rc;
+#ifdef YH_WINO_STAMPS
+    static unsigned long long *dbgbuf = nullptr;
+    const int nwg_dbg = cdiv(g.ntiles, TPB) * g.ncol;
+    if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
+    g.dbg = getenv("YH_WINO_DBG") && (size_t)nwg_dbg * 48 <= ((size_t)1 << 24) ? dbgbuf : nullptr;
+#endif
     hipLaunchKernelGGL((wino_kernel<NT, PIPE>), dim3(cdiv(g.ntiles, TPB) * g.ncol), dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("wino");
+#ifdef YH_WINO_STAMPS
+    if (g.dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)nwg_dbg * 6);
+        (void)hipMemcpy(h.data(), g.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double a = 0, b = 0, c = 0, rt = 0; unsigned long long lo = ~0ull, hi = 0;
+        for (int i = 0; i < nwg_dbg; ++i) {
+            a += (double)(h[6 * i + 1] - h[6 * i]); b += (double)(h[6 * i + 2] - h[6 * i + 1]); c += (double)(h[6 * i + 3] - h[6 * i + 2]);
+            rt += (double)(h[6 * i + 5] - h[6 * i + 4]);
+            if (h[6 * i + 4] < lo) lo = h[6 * i + 4];
+            if (h[6 * i + 5] > hi) hi = h[6 * i + 5];
+        }
+        const double mf = (double)(g.K / 8) * 16 * NT * 64;
+        fprintf(stderr, "[wino stamps] NT %d PIPE %d K %d N %d wgs %d: setup %.0f, loop %.0f (MFMA issue floor %.0f), epilogue %.0f cycles per workgroup = %.2f us (clock %.2f GHz); span %.1f us\n",
+                NT, PIPE, g.K, g.N, nwg_dbg, a / nwg_dbg, b / nwg_dbg, mf, c / nwg_dbg, rt / nwg_dbg / 100.0, (a + b + c) / rt * 0.1, (double)(hi - lo) / 100.0);
+    }
+#endif
     return 0;
 }
 
