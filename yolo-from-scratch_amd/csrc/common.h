@@ -52,6 +52,7 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // accurate exp (not __expf): parity with the CPU reference is 1e-4 relative on losses

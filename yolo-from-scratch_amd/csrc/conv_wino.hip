@@ -58,9 +58,10 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
 }
 
 template <int NT, int PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ? 2 : 1, PIPE == 1 ? (NT == 1 ? 3 : 2) : 1))) void wino_kernel(const Wino g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ? 2 : 1, PIPE == 1 ? (NT == 1 ? 3 : 2) : (PIPE == 3 && NT == 1 ? 2 : 1)))) void wino_kernel(const Wino g) {
     constexpr int BNW = 32 * NT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats)
+    constexpr int IMG_FLOATS = 6 * 4 * NT * 256;                   // training epilogue: six register images of 16 NT floats per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats) / images + tile offsets + stats
 
 #ifdef YH_WINO_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
         if (!tv) tg = 0;
         int b = fdiv(tg, g.tpi_magic, g.tpi_shift), r = tg - b * g.TPI;
         int ty = fdiv(r, g.tw_magic, g.tw_shift), tx = r - ty * g.TW;
+        // pixel index of the tile's top-left output, for the training epilogue (read after its barrier; -1 = no such tile)
+        if (wave == 0 && lh == 0) ((int *)(smem + IMG_FLOATS))[lr] = tv ? (b * g.H + 2 * ty) * g.W + 2 * tx : -1;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             int iy = 2 * ty - 1 + (rr ? rb : ra);
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
 
     // Two register sets (A, B), loop unrolled by two: the loads of one set are in flight behind the MFMAs of the
     // other.  No branches, selects or LDS in the loop.
-    f32x4 dA[2][4], uA[4][NT], dB[2][4], uB[4][NT];
+    f32x4 dA[2][4], uA[4][NT], dB[2][4], uB[4][NT], dC[2][4], uC[4][NT];      // dC / uC: PIPE == 3 only
     auto load_chunk = [&](int c, f32x4 (&d)[2][4], f32x4 (&u)[4][NT]) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
@@ -155,7 +158,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
 #ifdef YH_WINO_STAMPS
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (PIPE == 2) {
+    if constexpr (PIPE == 3) {
+        // three register sets: the loads of chunk c + 2 are issued before the MFMAs of chunk c (two chunks = 4096 MFMA cycles of
+        // cover; one chunk left ~1100 cycles of every 3200 waiting at 1 wave per SIMD -- stamps, 64 -> 64 at 40x40)
+        const int last = nchunks - 1;
+        load_chunk(0, dA, uA);
+        load_chunk(1, dB, uB);
+        for (int c = 0; c < nchunks; c += 3) {
+            load_chunk(c + 2 < last ? c + 2 : last, dC, uC);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(dA, uA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunks) {
+                load_chunk(c + 3 < last ? c + 3 : last, dA, uA);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(dB, uB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (c + 2 < nchunks) {
+                load_chunk(c + 4 < last ? c + 4 : last, dB, uB);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(dC, uC);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if constexpr (PIPE == 2) {
         load_chunk(0, dA, uA);
         for (int c = 0; c < nchunks; c += 2) {
             load_chunk(c + 1, dB, uB);
@@ -179,7 +206,148 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
 #ifdef YH_WINO_STAMPS
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- output transform.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
+    // ---- output transform, training form (no activation / residual / upsample / BatchNorm table) ----------------------------
+    // Y = A^T M A per tile.  The nu-contraction is lane-local: T[c] = (m0 + m1) + m2 | (m1 - m2) - m3 (output column c).  The
+    // xi-contraction needs three of the four waves' T: wave w produces output row w >> 1, column w & 1 of every tile, so the
+    // waves swap whole REGISTER IMAGES through LDS (six images, 16-byte writes and reads, lane-contiguous: conflict-free) and
+    // each stores its quarter of the outputs straight from the MFMA layout (32 consecutive channels = 128 bytes per row).
+    // Same values bit for bit as the general epilogue below ((T0 + T1) + T2, (T1 - T2) - T3); in-kernel stamps: that one
+    // took 11 000 cycles per workgroup at one wave per SIMD (64 4-byte LDS writes + 64 reads per lane, per-tile divisions).
+    if (!(g.act | g.up2 | (g.res != nullptr)) && g.bn_n == 0) {
+        float T[2][NT][16];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+                T[0][j][r] = m0 + m1 + m2;
+                T[1][j][r] = m1 - m2 - m3;
+            }
+        auto put = [&](int id, const float (&v)[NT][16]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4 *)(smem + ((size_t)((id * NT + j) * 4 + q) * 64 + lane) * 4) = f32x4{v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]};
+        };
+        auto get = [&](int id, float (&v)[NT][16]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 x = *(const f32x4 *)(smem + ((size_t)((id * NT + j) * 4 + q) * 64 + lane) * 4);
+                    v[j][4 * q] = x[0]; v[j][4 * q + 1] = x[1]; v[j][4 * q + 2] = x[2]; v[j][4 * q + 3] = x[3];
+                }
+        };
+        // images: 0 = T0[1], 1 = T1[0], 2 = T1[1], 3 = T2[0], 4 = T2[1], 5 = T3[0]
+        if (wave == 0) put(0, T[1]);
+        else if (wave == 1) { put(1, T[0]); put(2, T[1]); }
+        else if (wave == 2) { put(3, T[0]); put(4, T[1]); }
+        else put(5, T[0]);
+        __syncthreads();
+        float Y[NT][16], L1[NT][16], L2[NT][16];
+        if (wave == 0) {            // row 0, column 0: (T0[0] + T1[0]) + T2[0]
+            get(1, L1); get(3, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (T[0][j][r] + L1[j][r]) + L2[j][r];
+        } else if (wave == 1) {     // row 0, column 1: (T0[1] + T1[1]) + T2[1]
+            get(0, L1); get(4, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] + T[1][j][r]) + L2[j][r];
+        } else if (wave == 2) {     // row 1, column 0: (T1[0] - T2[0]) - T3[0]
+            get(1, L1); get(5, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - T[0][j][r]) - L2[j][r];
+        } else {                    // row 1, column 1: (T1[1] - T2[1]) - T3[1]
+            get(2, L1); get(4, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - L2[j][r]) - T[1][j][r];
+        }
+        // register r of this lane = tile (r & 3) + 8 (r >> 2) + 4 lh of the group: four consecutive offsets per 16-byte read
+        const int *toff = (const int *)(smem + IMG_FLOATS);
+        int tp[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const i32x4 x = *(const i32x4 *)(toff + 8 * q + 4 * lh);
+            tp[4 * q] = x[0]; tp[4 * q + 1] = x[1]; tp[4 * q + 2] = x[2]; tp[4 * q + 3] = x[3];
+        }
+        const int pc = (wave >> 1) * g.W + (wave & 1);
+        gfloat *const outg = yh_global(g.out);
+        const bool whole = tile0 + TPB <= g.ntiles && n0 + BNW <= g.N;       // wave-uniform
+        float cs[NT], cq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + 32 * j + lr;
+            const bool nok = n < g.N;
+            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+            cs[j] = cq[j] = 0.f;
+            if (whole) {
+                if (!g.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = Y[j][r] + bias;
+                        outg[(unsigned)((tp[r] + pc) * g.ldo + n)] = v;
+                        cs[j] += v;
+                        cq[j] += v * v;
+                    }
+                } else {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = outg[(unsigned)((tp[r] + pc) * g.ldo + n)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = Y[j][r] + bias + old[r];
+                        outg[(unsigned)((tp[r] + pc) * g.ldo + n)] = v;
+                        cs[j] += v;
+                        cq[j] += v * v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (nok && tp[r] >= 0) {
+                        gfloat *o = outg + (unsigned)((tp[r] + pc) * g.ldo + n);
+                        float v = Y[j][r] + bias;
+                        if (g.accumulate) v += *o;
+                        *o = v;
+                        cs[j] += v;
+                        cq[j] += v * v;
+                    }
+            }
+        }
+        if (g.stats) {
+            float *red = smem + IMG_FLOATS + 32;                          // [4 waves][BNW][2]
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float s = cs[j] + __shfl_xor(cs[j], 32), q = cq[j] + __shfl_xor(cq[j], 32);
+                if (lh == 0) { red[(wave * BNW + 32 * j + lr) * 2] = s; red[(wave * BNW + 32 * j + lr) * 2 + 1] = q; }
+            }
+            __syncthreads();
+            if (t < BNW && n0 + t < g.N) {
+                const float a0 = (red[t * 2] + red[(BNW + t) * 2]) + (red[(2 * BNW + t) * 2] + red[(3 * BNW + t) * 2]);
+                const float a1 = (red[t * 2 + 1] + red[(BNW + t) * 2 + 1]) + (red[(2 * BNW + t) * 2 + 1] + red[(3 * BNW + t) * 2 + 1]);
+                g.stats[((size_t)tgrp * 2 + 0) * g.N + n0 + t] = a0;
+                g.stats[((size_t)tgrp * 2 + 1) * g.N + n0 + t] = a1;
+            }
+        }
+#ifdef YH_WINO_STAMPS
+        if (g.dbg && t == 0) {
+            unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
+        return;
+    }
+
+    // ---- output transform, general form.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
     float *S = smem;                           // [xi 4][j 2][tile 32][ch BNW]
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -588,19 +756,23 @@ int launch_wino(Wino &g, hipStream_t st) {
     YH_REQUIRE(g.H % 2 == 0 && g.W % 2 == 0, "conv_wino: H and W must be even");
     YH_REQUIRE(g.K % (2 * KC) == 0 && g.K <= ZPAD && g.ldi % 4 == 0 && (((uintptr_t)g.in | (uintptr_t)g.U) & 15) == 0 && g.ldu >= g.N,
                "conv_wino: K must be a multiple of 16 (<= 2048), buffers 16-byte addressable");
-    YH_REQUIRE((int64_t)g.B * g.H * g.W * g.ldi < (1ll << 31), "conv_wino: input exceeds 32-bit element offsets");
+    YH_REQUIRE((int64_t)g.B * g.H * g.W * g.ldi < (1ll << 31) && (int64_t)g.B * g.H * g.W * g.ldo * (g.up2 ? 4 : 1) < (1ll << 31),
+               "conv_wino: tensors exceed 32-bit element offsets");
     g.TW = g.W / 2; g.TPI = (g.H / 2) * g.TW; g.ntiles = g.B * g.TPI;
     set_magic((unsigned)g.TW, g.tw_magic, g.tw_shift);
     set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
-    // many workgroups: two resident per CU with one register set hide each other's prologue / epilogue (measured
-    // 1.1-1.25x on the 160^2 / 80^2 layers); few workgroups: the software-pipelined variant (1.1x on 20^2 layers).
-    // Tried and dropped: prefetch distance 2 (three register sets: no change), compiler-scheduled or
+    // Enough tile groups (>= 800: the 160^2 ... 40^2 layers at batch 64): one register set at two waves per SIMD, the two
+    // resident workgroups of a CU hide each other's loads and epilogue (loop at 83 % of the MFMA issue rate by in-kernel
+    // stamps); fewer (20^2 layers): the software-pipelined variant at one wave per SIMD.  Measured after the FLAT -> global
+    // load fix, forward ms at batch 64 (PIPE 1 / 2 / 3): 80^2 64->64 0.200 / 0.241 / 0.246, 40^2 64->64 0.065 / 0.071 / 0.074,
+    // 40^2 128->128 0.183 / 0.189 / 0.195, 20^2 128->128 0.059 / 0.053 / 0.057, 20^2 256->256 0.199 / 0.183 / 0.188.
+    // Three register sets (prefetch distance 2) never win: what is left of the loop's stall at one wave per SIMD is not
+    // load latency (the strided 16-byte activation loads keep the L1 fill path busy).  Also dropped: compiler-scheduled or
     // sched_group_barrier-interleaved loads among the MFMAs (15-25 % slower than loads pinned ahead of them).
     static const int force = getenv("YH_WINO_PIPE") ? atoi(getenv("YH_WINO_PIPE")) : 0;
-    const int nblk = cdiv(g.ntiles, TPB) * cdiv(g.N, g.N <= 32 ? 32 : 64);
-    const int pipe = force ? force : (nblk >= 2048 ? 1 : 2);
-    if (g.N <= 32) return pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
-    return pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
+    const int pipe = force ? force : (cdiv(g.ntiles, TPB) >= 800 ? 1 : 2);
+    if (g.N <= 32) return pipe == 3 ? launch_nt<1, 3>(g, st) : pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
+    return pipe == 3 ? launch_nt<2, 3>(g, st) : pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
 }
 
 }  // namespace
