@@ -30,33 +30,16 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
     constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;
     constexpr int Q = CIN / 4, NT = COUT / 16;
     constexpr int MT = TH * 2 / 4;                        // 16-pixel row segments per wave (TH rows x 2 halves over 4 waves)
-    constexpr int NPX = IH * IW;
+    constexpr int NPX = IH * IW, NPC = NPX * Q, NX = (NPC + 255) / 256;
     // stride 2: even and odd input columns are stored as two planes so that the 16 pixels of a fragment stay contiguous
     constexpr int PLANE = S == 1 ? IW : (IW + 1) / 2;
-    __shared__ __attribute__((aligned(16))) float xs[Q * IH * (S == 1 ? IW : 2 * PLANE) * 4 + 4 * COUT * 2];
     constexpr int ROWSZ = (S == 1 ? IW : 2 * PLANE);     // pixels per stored input row
+    __shared__ __attribute__((aligned(16))) float xs[Q * IH * ROWSZ * 4 + 4 * COUT * 2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int col = lane & 15, kk = lane >> 4;
+    const int npatch = g.B * g.tiles_x * g.tiles_y;
 
-    int bid = blockIdx.x;
-    const int tx = bid % g.tiles_x;
-    bid /= g.tiles_x;
-    const int ty = bid % g.tiles_y, b = bid / g.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-
-    // ---- stage the halo patch: one 16-byte piece = (pixel, channel quad) ------------------------------------------------
-    for (int i = t; i < NPX * Q; i += 256) {
-        const int q = i % Q, p = i / Q;
-        const int py = p / IW, px = p - py * IW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
-            v = *(const f32x4 *)(g.in + ((size_t)(b * g.Hi + iy) * g.Wi + ix) * g.ldi + 4 * q);
-        const int sx = S == 1 ? px : (px & 1) * PLANE + (px >> 1);
-        *(f32x4 *)(xs + ((size_t)(q * IH + py) * ROWSZ + sx) * 4) = v;
-    }
-    // ---- the filter as B fragments: lane (col, kk) holds w[tap][4q + kk][n0 + col] ------------------------------------------
+    // ---- the filter as B fragments, once per (persistent) workgroup: lane (col, kk) holds w[tap][4q + kk][n0 + col] ---------
     float bw[9 * Q][NT];
 #pragma unroll
     for (int tq = 0; tq < 9 * Q; ++tq) {
@@ -65,14 +48,39 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) bw[tq][n] = g.w[((size_t)wt * CIN + 4 * q + kk) * g.ldw + 16 * n + col];
     }
-    __syncthreads();
+    float bias[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bias[n] = g.bias ? g.bias[16 * n + col] : 0.f;
 
-    // ---- multiply: wave w owns output rows {w, w + 4} (stride 1: 8 rows) or row w (stride 2), two 16-pixel halves each -----
-    f32x4 acc[MT][NT];
+    // ---- staging plan (fixed for the kernel): piece k of this thread = 16 bytes (patch pixel (py, px), channel quad q);
+    // gx = element offset from the patch origin, mx = LDS float offset | py << 16 | px << 24 (py = 255: past the end)
+    int gx[NX];
+    unsigned mx[NX];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int k = 0; k < NX; ++k) {
+        const int i = t + 256 * k;
+        const int q = i % Q, p = i / Q;
+        const int py = p / IW, px = p - py * IW;
+        const int sx = S == 1 ? px : (px & 1) * PLANE + (px >> 1);
+        gx[k] = (py * g.Wi + px) * g.ldi + 4 * q;
+        mx[k] = i < NPC ? (unsigned)(((q * IH + py) * ROWSZ + sx) * 4) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
+    }
+    f32x4 rx[NX];
+    auto fetch = [&](int pid) {
+        const int tx = pid % g.tiles_x;
+        const int rest = pid / g.tiles_x;
+        const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
+        const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+        const float *xb = g.in + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NX; ++k) {
+            const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = *(const f32x4 *)(xb + gx[k]);
+            rx[k] = v;
+        }
+    };
+
     int abase[MT];                                        // LDS float offset of the fragment's pixel `col` at tap (0,0), quad 0
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -81,48 +89,88 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         const int sx = S == 1 ? px : (px >> 1);           // (even input column -> plane 0)
         abase[m] = ((row * S) * ROWSZ + sx) * 4 + kk;
     }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        // stride 2: dx = 0, 2 read the even plane at +0 / +1 pixel, dx = 1 the odd plane
-        const int doff = S == 1 ? (dy * ROWSZ + dx) * 4 : (dy * ROWSZ + (dx == 1 ? PLANE : (dx >> 1))) * 4;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            float a[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = xs[q * IH * ROWSZ * 4 + abase[m] + doff];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[tap * Q + q][n], acc[m][n], 0, 0, 0);
-        }
-    }
 
-    // ---- epilogue: D register r of lane (col, kk) = pixel 4 kk + r of the segment, channel col ------------------------------
-    float csum[NT], csq[NT];
+    // A persistent workgroup walks the patches blockIdx.x, + gridDim.x, ...; the next patch's halo is in flight (registers)
+    // while the current one is multiplied and stored.
+    float csum[NT], csq[NT];                              // BatchNorm partial sums of ALL patches of this workgroup: one row
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        csum[n] = csq[n] = 0.f;
-        const float bias = g.bias ? g.bias[16 * n + col] : 0.f;
+    for (int n = 0; n < NT; ++n) csum[n] = csq[n] = 0.f;
+    int pid = blockIdx.x;
+    if (pid < npatch) fetch(pid);
+    for (; pid < npatch; pid += gridDim.x) {
+        __syncthreads();                                  // the previous patch's fragments are consumed
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int oy = oy0 + wave + 4 * (m >> 1);
+        for (int k = 0; k < NX; ++k)
+            if (t + 256 * k < NPC) *(f32x4 *)(xs + (mx[k] & 0xffffu)) = rx[k];
+        __syncthreads();
+        if (pid + (int)gridDim.x < npatch) fetch(pid + gridDim.x);
+
+        // ---- multiply: wave w owns output rows {w, w + 4} (8-row patches) or row w, two 16-pixel halves each -----------
+        f32x4 acc[MT][NT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ox = ox0 + 16 * (m & 1) + 4 * kk + r;
-                if (oy < g.Ho && ox < g.Wo) {
-                    float *o = g.out + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 16 * n + col;
-                    float v = acc[m][n][r] + bias;
-                    if (g.accumulate) v += *o;
-                    *o = v;
-                    csum[n] += v;
-                    csq[n] += v * v;
-                }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            // stride 2: dx = 0, 2 read the even plane at +0 / +1 pixel, dx = 1 the odd plane
+            const int doff = S == 1 ? (dy * ROWSZ + dx) * 4 : (dy * ROWSZ + (dx == 1 ? PLANE : (dx >> 1))) * 4;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                float a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = xs[q * IH * ROWSZ * 4 + abase[m] + doff];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[tap * Q + q][n], acc[m][n], 0, 0, 0);
             }
+        }
+
+        // ---- epilogue: D register r of lane (col, kk) = pixel 4 kk + r of the segment, channel col --------------------------
+        const int tx = pid % g.tiles_x;
+        const int rest = pid / g.tiles_x;
+        const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        if (oy0 + TH <= g.Ho && ox0 + TW <= g.Wo) {       // whole patch: no per-element tests
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float *o = g.out + ((size_t)(b * g.Ho + oy0 + wave + 4 * (m >> 1)) * g.Wo + ox0 + 16 * (m & 1) + 4 * kk) * g.ldo + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        float v = acc[m][n][r] + bias[n];
+                        if (g.accumulate) v += o[(size_t)r * g.ldo + 16 * n];
+                        o[(size_t)r * g.ldo + 16 * n] = v;
+                        csum[n] += v;
+                        csq[n] += v * v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int oy = oy0 + wave + 4 * (m >> 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ox = ox0 + 16 * (m & 1) + 4 * kk + r;
+                        if (oy < g.Ho && ox < g.Wo) {
+                            float *o = g.out + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 16 * n + col;
+                            float v = acc[m][n][r] + bias[n];
+                            if (g.accumulate) v += *o;
+                            *o = v;
+                            csum[n] += v;
+                            csq[n] += v * v;
+                        }
+                    }
+                }
         }
     }
     if (g.stats) {
-        float *red = xs + Q * IH * ROWSZ * 4;                      // [4 waves][COUT][2]
+        float *red = xs + Q * IH * ROWSZ * 4;                          // [4 waves][COUT][2]
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             float s = csum[n], q = csq[n];
@@ -448,6 +496,16 @@ int narrow_wgrad_launch(NarrowW g, float *dw, int cin_real, hipStream_t st) {
     return 0;
 }
 
+// persistent grid of the forward / stride-1 backward-data kernel (YH_NARROW_BLOCKS overrides for sweeps)
+int narrow_conv_grid(int npatch) {
+    static const int forced = [] {
+        const char *e = getenv("YH_NARROW_BLOCKS");
+        return e ? atoi(e) : 0;
+    }();
+    const int target = forced > 0 ? forced : 512;     // 2 per CU: measured 0.162 vs 0.183 ms (first layer), others equal at 1024
+    return npatch < target ? npatch : target;
+}
+
 int narrow_tiles(int Ho, int Wo, int Cin, int s, int &tx, int &ty) {
     const int TH = (s == 1 || Cin == 4) ? 8 : 4;
     tx = cdiv(Wo, 32);
@@ -464,7 +522,7 @@ extern "C" int yh_conv_narrow_ok(int Cin, int Cout, int k, int s) {
 extern "C" int yh_conv_narrow_blocks(int B, int Hi, int Wi, int Cin, int s) {
     const int Ho = (Hi - 1) / s + 1, Wo = (Wi - 1) / s + 1;
     int tx, ty;
-    return B * narrow_tiles(Ho, Wo, Cin, s, tx, ty);
+    return narrow_conv_grid(B * narrow_tiles(Ho, Wo, Cin, s, tx, ty));      // one partial row per persistent workgroup
 }
 
 extern "C" int yh_conv_narrow_dgrad_s2_ok(int Cin, int Cout) { return Cin == 16 && Cout == 32 ? 1 : 0; }
@@ -499,9 +557,10 @@ extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, 
     g.flip = flip_taps ? 1 : 0; g.accumulate = accumulate ? 1 : 0;
     const int nt = narrow_tiles(g.Ho, g.Wo, Cin, s, g.tiles_x, g.tiles_y);
     hipStream_t st = (hipStream_t)stream;
-    if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1>), dim3(B * nt), dim3(256), 0, st, g);
-    else if (Cin == 4) hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2>), dim3(B * nt), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2>), dim3(B * nt), dim3(256), 0, st, g);
+    const int grid = narrow_conv_grid(B * nt);
+    if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1>), dim3(grid), dim3(256), 0, st, g);
+    else if (Cin == 4) hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2>), dim3(grid), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow");
     return 0;
 }

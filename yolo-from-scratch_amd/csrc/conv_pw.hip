@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
     // flight while the last chunk of the current one is multiplied and while its epilogue stores drain, so load, MFMA and
     // store phases of the chip overlap instead of alternating (one tile per workgroup ran 7.5 + 13.6 + 7 us per round of
     // 512 workgroups on 128 -> 128 at 160x160: every workgroup loading, then multiplying, then storing at the same time).
+    float cs = 0.f, cq = 0.f;                                               // BatchNorm sums of ALL tiles of this workgroup: one row
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile, 0);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -548,8 +549,7 @@ __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
 #ifdef YH_PW_STAMPS
         st2 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- epilogue: bias / accumulate, 128-byte row stores, per-tile column sums ------------------------------------
-        float cs = 0.f, cq = 0.f;
+        // ---- epilogue: bias / accumulate, 128-byte row stores, column sums ---------------------------------------------
         if (cols_whole && m0 + BM <= g.M) {
             // full tile, all 32 columns in one tensor: no per-element tests; row offsets are compile-time multiples of ldo
             gfloat *const o0 = ob_u + (size_t)(m0 + wm * TMW * 32) * ldo_u + ((size_t)(4 * lh) * ldo_u + nl);
@@ -594,32 +594,32 @@ __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
                     }
                 }
         }
-        if (g.stats) {
-            float(*red)[32][2] = (float(*)[32][2])pw_as;                    // [4 waves][32][2]
-            cs += __shfl_xor(cs, 32);
-            cq += __shfl_xor(cq, 32);
-            __syncthreads();                                                // all waves are done with the A tile
-            if (lh == 0) { red[wave][lr][0] = cs; red[wave][lr][1] = cq; }
-            __syncthreads();
-            if (t < 32 * WN) {
-                const int cw = t >> 5, cl = t & 31, nn = (blockIdx.y * WN + cw) * 32 + cl;
-                if (nn < g.N) {
-                    float a0s = 0.f, a1s = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WM; ++w) { a0s += red[w * WN + cw][cl][0]; a1s += red[w * WN + cw][cl][1]; }
-                    gfloat *sp = nn >= g.N1 ? yh_global(g.stats2) : yh_global(g.stats);    // each tensor has its own [tiles][2][C] partials
-                    const int C = nn >= g.N1 ? g.N - g.N1 : g.N1, nnl = nn >= g.N1 ? nn - g.N1 : nn;
-                    sp[((size_t)tile * 2 + 0) * C + nnl] = a0s;
-                    sp[((size_t)tile * 2 + 1) * C + nnl] = a1s;
-                }
-            }
-        }
 #ifdef YH_PW_STAMPS
         if (g.dbg && t == 0 && blockIdx.y == 0) {
             unsigned long long *d = g.dbg + (size_t)tile * 6;
             d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
+    }
+    if (g.stats) {
+        float(*red)[32][2] = (float(*)[32][2])pw_as;                        // [4 waves][32][2]
+        cs += __shfl_xor(cs, 32);
+        cq += __shfl_xor(cq, 32);
+        __syncthreads();                                                    // all waves are done with the A tile
+        if (lh == 0) { red[wave][lr][0] = cs; red[wave][lr][1] = cq; }
+        __syncthreads();
+        if (t < 32 * WN) {
+            const int cw = t >> 5, cl = t & 31, nn = (blockIdx.y * WN + cw) * 32 + cl;
+            if (nn < g.N) {
+                float a0s = 0.f, a1s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { a0s += red[w * WN + cw][cl][0]; a1s += red[w * WN + cw][cl][1]; }
+                gfloat *sp = nn >= g.N1 ? yh_global(g.stats2) : yh_global(g.stats);    // each tensor has its own [workgroups][2][C] partials
+                const int C = nn >= g.N1 ? g.N - g.N1 : g.N1, nnl = nn >= g.N1 ? nn - g.N1 : nn;
+                sp[((size_t)blockIdx.x * 2 + 0) * C + nnl] = a0s;
+                sp[((size_t)blockIdx.x * 2 + 1) * C + nnl] = a1s;
+            }
+        }
     }
 }
 
@@ -813,6 +813,14 @@ inline int pw_tile_slots(int BM) {
     (void)BM;
     return 512;                                // 2 workgroups per CU (67 KB of LDS at 128 rows; ~200 VGPRs at 64)
 }
+// grid.x of the LDS-staged persistent kernel = rows of BatchNorm partial sums it writes
+inline int pw_tile_gx(int64_t M, int N) {
+    const int BM = pw_tile_bm(N), WN = N > 64 ? 4 : (N > 32 ? 2 : 1);
+    const int ntile = cdiv((int)M, BM), ncol = cdiv(N, 32 * WN);
+    int gx = cdiv(pw_tile_slots(BM), ncol);
+    if (gx > ntile) gx = ntile;
+    return cdiv(ntile, cdiv(ntile, gx));                                   // same number of rounds, evenly filled
+}
 inline bool pw_use_tile(int K, int N) {
     static const bool on = !(getenv("YH_PW_TILE") && atoi(getenv("YH_PW_TILE")) == 0);
     (void)N;
@@ -869,10 +877,7 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
         const int WN = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
         const int BM = pw_tile_bm(g.N);
         const int ntile = cdiv(g.M, BM), ncol = cdiv(g.N, 32 * WN);
-        const int slots = pw_tile_slots(BM);                                 // resident workgroups on the chip
-        int gx = cdiv(slots, ncol);
-        if (gx > ntile) gx = ntile;
-        gx = cdiv(ntile, cdiv(ntile, gx));                                   // same number of rounds, evenly filled
+        const int gx = pw_tile_gx(g.M, g.N);
         dim3 tg(gx, ncol);
 #ifdef YH_PW_STAMPS
         static unsigned long long *dbgbuf = nullptr;
@@ -940,7 +945,7 @@ extern "C" int yh_conv_pw_bwd_data_bn_rows(int64_t M, int K, int Cin) {
 
 extern "C" int yh_conv_pw_blocks(int64_t M, int K, int Cout) {
     if (pw_use_stream(M, K, Cout)) return pw_stream_blocks(M);
-    if (pw_use_tile(K, Cout)) return cdiv((int)M, pw_tile_bm(Cout));
+    if (pw_use_tile(K, Cout)) return pw_tile_gx(M, Cout);
     const int NT = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
     const int TM = (NT <= 2 && cdiv((int)M, 256) * cdiv(Cout, 32 * NT) >= 1024) ? 2 : 1;
     return cdiv((int)M, 128 * TM);
