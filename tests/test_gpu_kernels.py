@@ -269,7 +269,7 @@ def test_fused_inference_conv_with_folded_bn(Cin, Cout, k, s, res, up, act):
     assert rel_err(out.permute(0, 3, 1, 2), y) < 1e-4
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 50, 38), (3, 33, 47)])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 50, 38), (3, 33, 47), (8, 250, 320)])
 def test_stem_conv_direct_kernel(B, H, W):
     """yh_conv_stem_fwd (first layer, 3->16, k3 s2 p1, NHWC4 input) against fp64 torch and against the generic kernel's
     BatchNorm partial-sum contract; odd sizes and a ragged last workgroup included."""
@@ -392,7 +392,9 @@ def test_small_m_tap_split_inference_conv(B, H, W, Cin, Cout, s, res, up):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 24, 64, 16, 16, 1), (3, 23, 45, 16, 16, 1), (2, 32, 96, 16, 32, 2), (2, 21, 67, 16, 32, 2),
-                                             (1, 8, 32, 16, 16, 1)])
+                                             (1, 8, 32, 16, 16, 1),
+                                             # more patches than persistent workgroups (several patches per workgroup, ragged edges)
+                                             (16, 125, 160, 16, 16, 1), (16, 128, 190, 16, 32, 2)])
 def test_narrow_direct_conv_kernel(B, H, W, Cin, Cout, s):
     """yh_conv_narrow (LDS halo patch + register-resident filter on the 16x16x4 MFMA) = fp64 torch for the two narrow layer
     shapes: forward with bias + BatchNorm partial sums into a channel slice of a wider buffer, ragged patches, and the

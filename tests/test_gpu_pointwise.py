@@ -34,7 +34,10 @@ def pack(L, lib, w, wq_f, wq_b, ldwf, ldwb, koff=0, noff=0):
 
 CASES = [(300, 32, 16), (1000, 64, 64), (777, 128, 128), (260, 256, 128), (513, 192, 64), (129, 64, 24), (4100, 32, 32), (96, 384, 136),
          # M >= 32768 with small K: the streaming form (weights in registers, fixed grid, one partial row per workgroup)
-         (40003, 32, 32), (70001, 64, 64), (33000, 32, 128), (50000, 16, 16), (36000, 64, 24), (32768, 32, 16), (33000, 128, 32)]
+         (40003, 32, 32), (70001, 64, 64), (33000, 32, 128), (50000, 16, 16), (36000, 64, 24), (32768, 32, 16), (33000, 128, 32),
+         # K >= 64 with more pixel tiles than persistent workgroups: the LDS-staged kernel walks several tiles per workgroup
+         # (next tile prefetched, one partial row per workgroup), ragged last tile, N = 128 / 64 / 24 wave layouts
+         (140001, 128, 128), (70003, 128, 64), (150001, 96, 24), (40000, 256, 256)]
 
 
 @pytest.mark.parametrize("M,Cin,Cout", CASES)
@@ -78,7 +81,8 @@ def test_pointwise_forward_and_backward_data(M, Cin, Cout):
 
 
 @pytest.mark.parametrize("M,Cin,c1,c2", [(500, 64, 32, 32), (1300, 32, 16, 16), (260, 256, 128, 128), (333, 128, 64, 40),
-                                         (45000, 64, 32, 32), (60001, 32, 16, 16)])          # last two: streaming form
+                                         (45000, 64, 32, 32), (60001, 32, 16, 16),           # these two: streaming form
+                                         (70001, 128, 64, 64), (50002, 128, 32, 32)])         # LDS-staged form, several tiles per workgroup
 def test_pointwise_sibling_pair_forward_and_backward_data(M, Cin, c1, c2):
     """two convs reading the same x: fused forward (two outputs, own bias / partial sums) and fused backward-data (K from
     two tensors) equal the two separate convolutions"""
