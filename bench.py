@@ -278,8 +278,8 @@ def main():
                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                               "traffic_note": traffic_note + "; algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
                               "kernel": "forward convolutions: wino_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
-                                        "the algorithmic multiplies) + pw_gemm_kernel / pw_stream_kernel (1x1) + gather_gemm_kernel (stride-2, "
-                                        "wide 1x1, head outputs) + narrow_conv_kernel (16-channel 3x3 layers, stem[3]) + stem_conv_kernel (first layer, VALU)",
+                                        "the algorithmic multiplies) + pw_tile_kernel / pw_stream_kernel (1x1) + gather_gemm_kernel (stride-2, "
+                                        "head outputs) + narrow_conv_kernel (16-channel 3x3 layers, stem[3], stem[0])",
                               "narrow_ms_per_step": round(per_kind.get(L.OP_CONV_NARROW, 0.0), 3),
                               "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
                               "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),

@@ -20,7 +20,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from provenance import stamp
 
-FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_stream_kernel", "stem_conv_kernel", "bf16_gemm_kernel", "narrow_conv_kernel")
+FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "stem_conv_kernel", "bf16_gemm_kernel",
+            "narrow_conv_kernel")
+DGRAD_ONLY = ("narrow_dgrad_s2_kernel",)
 WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "wgrad_reduce")
 
 
@@ -38,6 +40,8 @@ def family(name, phase):
     n = short(name)
     if any(k in n for k in WGRAD):
         return "wgrad:" + n
+    if n in DGRAD_ONLY:
+        return "dgrad:" + n
     if n in FWD_CONV or any(n.startswith(k) for k in FWD_CONV):
         return ("fwd_conv:" if phase == "fwd" else "dgrad:") + n
     return "other:" + n
