@@ -157,6 +157,18 @@ int yh_conv_narrow_bwd_weight_ok(int Cin, int cin_real, int Cout, int k, int s);
 int64_t yh_conv_narrow_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int s);
 int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats, int B,
                               int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
+/* The narrow-layer kernels with bf16 storage (bf16 path, BASELINE configs 3-4): activations, activation gradients and the
+ * weight packs of yh_bf16_pack_multi ([tap][kpad / 8][ld][8]) are bf16 in HBM; they are widened when parked in LDS and the fp32
+ * MFMA loop of the fp32 kernels runs unchanged (these layers are bound by HBM bytes and latency, products of bf16 values are
+ * exact in fp32).  Stored results are rounded to bf16, BatchNorm partial sums are taken over the rounded values, weight
+ * gradients are fp32.  Same contracts as the fp32 entry points otherwise; the first layer reads the first 4 channels of its
+ * (8-channel padded) input.  Same results as yh_bf16_conv_fwd / _bwd_data / _bwd_weight to fp32 accumulation order. */
+int yh_bf16_conv_narrow(const void *x, int ldx, const void *w, int ldw, int kpad, const float *bias, void *y, int ldy, float *bn_partials,
+                        int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream);
+int yh_bf16_conv_narrow_dgrad_s2(const void *dy, int lddy, const void *wb, int ldwb, int kpad, void *dx, int lddx, int B, int Hi, int Wi,
+                                 int Cin, int Cout, int accumulate, void *stream);
+int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *ws, int64_t ws_floats, int B, int Hi,
+                                   int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
 /* Winograd F(2x2,3x3) path for 3x3 / stride-1 / pad-1 convolutions with even H, W and K % 16 == 0 (K = Cin forward,
  * Cout backward): the same results as yh_conv_fwd / yh_conv_bwd_data to fp32 rounding with 4/9 of the multiplies.
  * yh_wino_weights transforms OIHW weights into U[16][K][ldu] (backward = 0: K = Cin, N = Cout; backward = 1: the
@@ -421,7 +433,10 @@ enum {
     YH_OP_FOLD_OIHW_MULTI, YH_OP_CONV_WINO_FWD_FUSED, YH_OP_CONV_PW_FWD_FUSED,  /* slots of YH_OP_CONV_FWD_FUSED */
     YH_OP_CONV_NARROW,  /* p: x, w, bias, y, partials;  i: ldx, ldw, ldy, B, H, W, Cin, Cout, s, flip_taps, accumulate */
     YH_OP_CONV_NARROW_DGRAD_S2,  /* slots of YH_OP_CONV_BWD_DATA */
-    YH_OP_CONV_NARROW_BWD_WEIGHT /* slots of YH_OP_CONV_BWD_WEIGHT */
+    YH_OP_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT */
+    YH_OP_BF16_CONV_NARROW,       /* slots of YH_OP_CONV_NARROW + i[11] = kpad (padded K rows per tap of the bf16 pack) */
+    YH_OP_BF16_CONV_NARROW_DGRAD_S2,   /* slots of YH_OP_CONV_BWD_DATA + i[11] = kpad */
+    YH_OP_BF16_CONV_NARROW_BWD_WEIGHT  /* slots of YH_OP_CONV_BWD_WEIGHT */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

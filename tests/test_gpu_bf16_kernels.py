@@ -340,3 +340,78 @@ def test_loss_writes_padded_bf16_head_gradient():
     for a, b in zip(d32, d16):
         assert torch.equal(b[..., :3 * ch], a.reshape(a.shape[0], a.shape[1], a.shape[2], 3 * ch).to(torch.bfloat16))
         assert bool((b[..., 3 * ch:] == 0).all())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s", [(2, 24, 64, 16, 16, 1), (3, 23, 45, 16, 16, 1), (2, 32, 96, 16, 32, 2), (2, 21, 67, 16, 32, 2),
+                                             (2, 64, 96, 3, 16, 2), (3, 37, 51, 3, 16, 2), (16, 125, 160, 16, 16, 1)])
+def test_bf16_narrow_layer_kernels(B, H, W, Cin, Cout, s):
+    """The narrow-layer direct kernels with bf16 storage (yh_bf16_conv_narrow / _dgrad_s2 / _bwd_weight: bf16 activations and
+    packs widened into LDS, fp32 MFMA loop) against fp64 torch on the bf16-rounded operands and against the generic bf16
+    kernels: forward with bias + BatchNorm partials of the STORED values into a channel slice, stride-1 (flipped taps) and
+    stride-2 backward-data with accumulate, weight gradient (fp32, bitwise reproducible).  Last case: more patches than
+    persistent workgroups."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(H * W + s + Cin)
+    x = bf(torch.randn(B, Cin, H, W))
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    wq = bf(w)
+    bias = torch.randn(Cout)
+    ref = F.conv2d(x.double(), wq.double(), bias.double(), s, 1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    cin = rup8(Cin)
+    cin_k = 4 if Cin <= 4 else Cin                 # channels the narrow kernel reads
+    st = torch.cuda.current_stream().cuda_stream
+    xg = nhwc_bf16(x, cpad=cin, ld=cin + 8, off=8)
+    xv = xg.view(-1)[8:]
+    wf, ldf, wb, ldb = pack(L, w.cuda(), cin)
+    assert lib.yh_conv_narrow_ok(cin_k, Cout, 3, s) == 1
+    nblk = lib.yh_conv_narrow_blocks(B, H, W, cin_k, s)
+    part = torch.zeros(nblk * 2 * Cout, device="cuda")
+    ld = Cout + 8
+    ybuf = torch.full((B, Ho, Wo, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    yv = ybuf.view(-1)[8:]
+    L.check(lib.yh_bf16_conv_narrow(xv.data_ptr(), cin + 8, wf.data_ptr(), ldf, cin, bias.cuda().data_ptr(), yv.data_ptr(), ld,
+                                    part.data_ptr(), B, H, W, cin_k, Cout, s, 0, 0, st), "bf16 narrow fwd")
+    y = ybuf[..., 8:].float().permute(0, 3, 1, 2)
+    assert rel_err(y, ref) < BF16_OUT_TOL
+    assert bool((ybuf[..., :8] == 7.0).all())
+    ps = part.view(nblk, 2, Cout).sum(0).cpu().double()
+    yd = y.double().cpu()
+    assert rel_err(ps[0], yd.sum((0, 2, 3))) < 1e-3 and rel_err(ps[1], (yd * yd).sum((0, 2, 3))) < 1e-4
+    # the generic bf16 kernel on the same operands: same values up to the rounding of the last bf16 bit
+    y2buf = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.yh_bf16_conv_fwd(xv.data_ptr(), cin + 8, wf.data_ptr(), ldf, bias.cuda().data_ptr(), y2buf.data_ptr(), Cout, 0, None,
+                                 B, H, W, cin, Cout, 3, s, st), "generic fwd")
+    assert rel_err(ybuf[..., 8:].float(), y2buf.float()) < BF16_OUT_TOL
+    # ---- backward-data ---------------------------------------------------------------------------------------------
+    dy = bf(torch.randn(B, Cout, Ho, Wo))
+    kp = rup8(Cout)
+    dyg = nhwc_bf16(dy, cpad=kp)
+    if Cin >= 8:
+        want_dx = F.conv_transpose2d(dy.double(), wq.double(), None, s, 1, output_padding=(H + 2 - 3 - (Ho - 1) * s, W + 2 - 3 - (Wo - 1) * s))
+        dxbuf = torch.full((B, H, W, cin + 8), 5.0, dtype=torch.bfloat16, device="cuda")
+        dxv = dxbuf.view(-1)[8:]
+        for acc in (0, 1):
+            if s == 1:
+                L.check(lib.yh_bf16_conv_narrow(dyg.data_ptr(), kp, wb.data_ptr(), ldb, kp, None, dxv.data_ptr(), cin + 8, None, B, H, W,
+                                                Cout, Cin, 1, 1, acc, st), "bf16 narrow dgrad")
+            else:
+                assert lib.yh_conv_narrow_dgrad_s2_ok(Cin, Cout) == 1
+                L.check(lib.yh_bf16_conv_narrow_dgrad_s2(dyg.data_ptr(), kp, wb.data_ptr(), ldb, kp, dxv.data_ptr(), cin + 8, B, H, W, Cin,
+                                                         Cout, acc, st), "bf16 narrow dgrad s2")
+            dx = dxbuf[..., 8:8 + Cin].float().permute(0, 3, 1, 2)
+            assert rel_err(dx, (1 + acc) * want_dx) < (1 + acc) * BF16_OUT_TOL
+            assert bool((dxbuf[..., :8] == 5.0).all())
+    # ---- backward-weight -------------------------------------------------------------------------------------------
+    want_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, 1)
+    assert lib.yh_conv_narrow_bwd_weight_ok(cin_k, min(Cin, cin_k), Cout, 3, s) == 1
+    nws = int(lib.yh_conv_narrow_bwd_weight_ws(B, H, W, cin_k, Cout, s))
+    ws = torch.empty(nws, device="cuda")
+    dw = torch.full((Cout, Cin, 3, 3), 9.0, device="cuda")
+    args = (xv.data_ptr(), cin + 8, dyg.data_ptr(), kp)
+    L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw.data_ptr(), ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
+    assert rel_err(dw, want_dw) < F32_OUT_TOL
+    dw2 = torch.empty_like(dw)
+    L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw2.data_ptr(), ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
+    assert torch.equal(dw, dw2)

@@ -32,7 +32,8 @@ class YhOp(C.Structure):
  OP_CONV_PW_BWD_DATA, OP_CONV_STEM_FWD, OP_PACK_WEIGHTS_S2M, OP_CONV_BWD_DATA_S2M, OP_CONV_PW_FWD2, OP_NOP,
  OP_BF16_PACK_MULTI, OP_BF16_CONV_FWD, OP_BF16_CONV_BWD_DATA, OP_BF16_CONV_BWD_WEIGHT, OP_BF16_COLSUM, OP_BF16_BN_SILU_FWD,
  OP_BF16_BN_SILU_BWD_REDUCE, OP_BF16_BN_SILU_BWD_APPLY, OP_BF16_MAXPOOL5_FWD, OP_BF16_MAXPOOL5_BWD,
- OP_FOLD_OIHW_MULTI, OP_CONV_WINO_FWD_FUSED, OP_CONV_PW_FWD_FUSED, OP_CONV_NARROW, OP_CONV_NARROW_DGRAD_S2, OP_CONV_NARROW_BWD_WEIGHT) = range(1, 52)
+ OP_FOLD_OIHW_MULTI, OP_CONV_WINO_FWD_FUSED, OP_CONV_PW_FWD_FUSED, OP_CONV_NARROW, OP_CONV_NARROW_DGRAD_S2, OP_CONV_NARROW_BWD_WEIGHT, OP_BF16_CONV_NARROW, OP_BF16_CONV_NARROW_DGRAD_S2,
+ OP_BF16_CONV_NARROW_BWD_WEIGHT) = range(1, 55)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -72,6 +73,9 @@ _SIGS = {
     "yh_conv_narrow_blocks": (i32, [i32, i32, i32, i32, i32]),
     "yh_conv_narrow_dgrad_s2_ok": (i32, [i32, i32]),
     "yh_conv_narrow_bwd_weight_ok": (i32, [i32, i32, i32, i32, i32]),
+    "yh_bf16_conv_narrow": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_narrow_dgrad_s2": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_narrow_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_narrow_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32]),
     "yh_conv_narrow_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_narrow_dgrad_s2": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),

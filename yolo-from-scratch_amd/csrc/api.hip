@@ -117,6 +117,14 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_NARROW_BWD_WEIGHT:  /* same argument slots as YH_OP_CONV_BWD_WEIGHT (k = 3 implied) */
             return yh_conv_narrow_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
                                              o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[9], st);
+        case YH_OP_BF16_CONV_NARROW:
+            return yh_bf16_conv_narrow(p[0], i[0], p[1], i[1], i[11], (const float *)p[2], p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6],
+                                       i[7], i[8], i[9], i[10], st);
+        case YH_OP_BF16_CONV_NARROW_DGRAD_S2:
+            return yh_bf16_conv_narrow_dgrad_s2(p[0], i[0], p[1], i[1], i[11], p[2], i[2], i[3], i[4], i[5], i[6], i[7], i[10], st);
+        case YH_OP_BF16_CONV_NARROW_BWD_WEIGHT:
+            return yh_bf16_conv_narrow_bwd_weight(p[0], i[0], p[1], i[1], (float *)p[2], (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], i[6],
+                                                  i[7], i[9], st);
         case YH_OP_FOLD_OIHW_MULTI:
             return yh_fold_oihw_multi(p[0], i[0], st);
         case YH_OP_CONV_WINO_FWD_FUSED:     /* slots of YH_OP_CONV_FWD_FUSED (k = 3, s = 1 implied) */
@@ -305,7 +313,7 @@ extern "C" int yh_run(yh_context *ctx, const yh_op *ops, int n, void *stream, in
         const int kind = ops[k].kind;
         const bool sync_op = kind == YH_OP_FORK || kind == YH_OP_JOIN;
         const bool auto_side = (kind == YH_OP_CONV_BWD_WEIGHT || kind == YH_OP_CONV_WINO_BWD_WEIGHT ||
-                                kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_CONV_NARROW_BWD_WEIGHT || kind == YH_OP_COLSUM || kind == YH_OP_BF16_CONV_BWD_WEIGHT ||
+                                kind == YH_OP_CONV_PW_BWD_WEIGHT || kind == YH_OP_CONV_NARROW_BWD_WEIGHT || kind == YH_OP_BF16_CONV_NARROW_BWD_WEIGHT || kind == YH_OP_COLSUM || kind == YH_OP_BF16_CONV_BWD_WEIGHT ||
                                 kind == YH_OP_BF16_COLSUM);
         int sr = 0;
         if (sync_op || auto_side || ops[k].lane == 1) sr = side_ready(ctx);

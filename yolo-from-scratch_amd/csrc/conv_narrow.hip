@@ -15,17 +15,51 @@
 
 namespace {
 
+// Storage type of activations / activation gradients / weight packs: float, or bf16 for the bf16 path (BASELINE configs 3-4).
+// The bf16 forms load 8-byte pieces (4 channels), widen them when they are parked in LDS and run the SAME fp32 MFMA loop --
+// the layers are bound by HBM bytes and latency, not by the matrix rate, and products of bf16 values are exact in fp32.
+// Stored results are rounded to bf16 and the BatchNorm sums are taken over the ROUNDED values, as in conv_bf16.hip.
+typedef __bf16 nbf16;
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct NarrowIO;
+template <> struct NarrowIO<float> {
+    static __device__ __forceinline__ f32x4 load4(const float *p) { return *(const f32x4 *)p; }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ float store1(float *p, float v) { *p = v; return v; }
+    // element (tap, k, n) of a weight pack [tap][K][ld]
+    static __device__ __forceinline__ float weight(const float *w, int tap, int k, int n, int K, int kpad, int ld) {
+        (void)kpad;
+        return w[((size_t)tap * K + k) * ld + n];
+    }
+};
+template <> struct NarrowIO<nbf16> {
+    static __device__ __forceinline__ f32x4 load4(const nbf16 *p) { return __builtin_convertvector(*(const nbf16x4 *)p, f32x4); }
+    static __device__ __forceinline__ float load1(const nbf16 *p) { return (float)*p; }
+    static __device__ __forceinline__ float store1(nbf16 *p, float v) { const nbf16 h = (nbf16)v; *p = h; return (float)h; }
+    // element (tap, k, n) of a bf16 pack [tap][kpad / 8][ld][8] (yh_bf16_pack_multi)
+    static __device__ __forceinline__ float weight(const nbf16 *w, int tap, int k, int n, int K, int kpad, int ld) {
+        (void)K;
+        return (float)w[(((size_t)tap * (kpad >> 3) + (k >> 3)) * ld + n) * 8 + (k & 7)];
+    }
+};
+
 struct Narrow {
-    const float *in, *w, *bias;     // w: [tap][CIN][ldw] (forward pack) or [tap][COUT_of_conv = K][ldw] (backward pack)
-    float *out, *stats;
+    const void *in, *w;             // w: [tap][CIN][ldw] (forward pack) or [tap][COUT_of_conv = K][ldw] (backward pack); bf16: see NarrowIO
+    const float *bias;
+    void *out;
+    float *stats;
+    int kpad;                       // bf16 packs: padded K rows per tap
     int ldi, ldw, ldo;
     int B, Hi, Wi, Ho, Wo;
     int tiles_x, tiles_y;
     int flip, accumulate;
 };
 
-template <int CIN, int COUT, int S>
+template <int CIN, int COUT, int S, typename T>
 __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
+    typedef NarrowIO<T> IO;
+    const T *const gin = (const T *)g.in;
+    T *const gout = (T *)g.out;
     constexpr int TW = 32, TH = (S == 1 || CIN == 4) ? 8 : 4;   // output patch
     constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;
     constexpr int Q = CIN / 4, NT = COUT / 16;
@@ -46,7 +80,7 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         const int tap = tq / Q, q = tq - tap * Q;
         const int wt = g.flip ? 8 - tap : tap;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bw[tq][n] = g.w[((size_t)wt * CIN + 4 * q + kk) * g.ldw + 16 * n + col];
+        for (int n = 0; n < NT; ++n) bw[tq][n] = IO::weight((const T *)g.w, wt, 4 * q + kk, 16 * n + col, CIN, g.kpad, g.ldw);
     }
     float bias[NT];
 #pragma unroll
@@ -71,12 +105,12 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         const int rest = pid / g.tiles_x;
         const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
         const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
-        const float *xb = g.in + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
+        const T *xb = gin + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = *(const f32x4 *)(xb + gx[k]);
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = IO::load4(xb + gx[k]);
             rx[k] = v;
         }
     };
@@ -136,14 +170,14 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         if (oy0 + TH <= g.Ho && ox0 + TW <= g.Wo) {       // whole patch: no per-element tests
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                float *o = g.out + ((size_t)(b * g.Ho + oy0 + wave + 4 * (m >> 1)) * g.Wo + ox0 + 16 * (m & 1) + 4 * kk) * g.ldo + col;
+                T *o = gout + ((size_t)(b * g.Ho + oy0 + wave + 4 * (m >> 1)) * g.Wo + ox0 + 16 * (m & 1) + 4 * kk) * g.ldo + col;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         float v = acc[m][n][r] + bias[n];
-                        if (g.accumulate) v += o[(size_t)r * g.ldo + 16 * n];
-                        o[(size_t)r * g.ldo + 16 * n] = v;
+                        if (g.accumulate) v += IO::load1(o + (size_t)r * g.ldo + 16 * n);
+                        v = IO::store1(o + (size_t)r * g.ldo + 16 * n, v);
                         csum[n] += v;
                         csq[n] += v * v;
                     }
@@ -158,10 +192,10 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
                     for (int r = 0; r < 4; ++r) {
                         const int ox = ox0 + 16 * (m & 1) + 4 * kk + r;
                         if (oy < g.Ho && ox < g.Wo) {
-                            float *o = g.out + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 16 * n + col;
+                            T *o = gout + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 16 * n + col;
                             float v = acc[m][n][r] + bias[n];
-                            if (g.accumulate) v += *o;
-                            *o = v;
+                            if (g.accumulate) v += IO::load1(o);
+                            v = IO::store1(o, v);
                             csum[n] += v;
                             csq[n] += v * v;
                         }
@@ -200,8 +234,11 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
 // tile shares its taps' weights; the A fragment (lane = j, k = 4 consecutive dY channels) is a conflict-free ds_read_b32 of
 // the staged dY patch.  A workgroup owns 8 dX rows x 64 columns; each wave takes one even and one odd row (balanced: 48 + 96
 // k-steps).  No zero-stuffed taps, no masked half tiles, every dY element read from HBM once.
-template <int KC, int NC>       // KC = dY channels (32), NC = dX channels (16)
+template <int KC, int NC, typename T>       // KC = dY channels (32), NC = dX channels (16)
 __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
+    typedef NarrowIO<T> IO;
+    const T *const gin = (const T *)g.in;
+    T *const gout = (T *)g.out;
     constexpr int TW = 64, TH = 8;                         // dX patch
     constexpr int PW = TW / 2 + 1, PH = TH / 2 + 1;        // dY patch (one extra row / column for the +1 neighbours)
     constexpr int Q = KC / 4;
@@ -220,7 +257,7 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
         const int pr = p / PW, pc = p - pr * PW;
         const int oy = a0 + pr, ox = b0 + pc;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (oy < g.Hi && ox < g.Wi) v = *(const f32x4 *)(g.in + ((size_t)(b * g.Hi + oy) * g.Wi + ox) * g.ldi + 4 * q);
+        if (oy < g.Hi && ox < g.Wi) v = IO::load4(gin + ((size_t)(b * g.Hi + oy) * g.Wi + ox) * g.ldi + 4 * q);
         *(f32x4 *)(ds + ((size_t)(q * PH + pr) * PW + pc) * 4) = v;
     }
     // weights: backward pack wb[tap][co][ldw] (K = co, N = ci); lane (col = ci, kk) holds w[tap][4q + kk][col]
@@ -228,7 +265,7 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
 #pragma unroll
     for (int tq = 0; tq < 9 * Q; ++tq) {
         const int tap = tq / Q, q = tq - tap * Q;
-        bw[tq] = g.w[((size_t)tap * KC + 4 * q + kk) * g.ldw + col];
+        bw[tq] = IO::weight((const T *)g.w, tap, 4 * q + kk, col, KC, g.kpad, g.ldw);
     }
     __syncthreads();
 #pragma unroll
@@ -259,10 +296,10 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
                     for (int r = 0; r < 4; ++r) {
                         const int x = x0 + 2 * (16 * seg + 4 * kk + r) + pxp;
                         if (x < g.Wo) {
-                            float *o = g.out + ((size_t)(b * g.Ho + y) * g.Wo + x) * g.ldo + col;
+                            T *o = gout + ((size_t)(b * g.Ho + y) * g.Wo + x) * g.ldo + col;
                             float v = acc[r];
-                            if (g.accumulate) v += *o;
-                            *o = v;
+                            if (g.accumulate) v += IO::load1(o);
+                            IO::store1(o, v);
                         }
                     }
                 }
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
 // flight under the MFMAs of the current one), keeps the 9 (x COUT/16) accumulator tiles in registers the whole time and
 // writes one raw slab at the end; a fixed-order reduction turns the slabs into OIHW.  Every x and dY element is read once.
 struct NarrowW {
-    const float *x, *dy;
+    const void *x, *dy;
     float *ws;
     int ldx, lddy;
     int B, Hi, Wi, Ho, Wo;
@@ -300,9 +337,10 @@ template <int CIN, int COUT, int S> struct NarrowWCfg {
     static constexpr int SLAB = RG * NB * 256;
 };
 
-template <int CIN, int COUT, int S>
+template <int CIN, int COUT, int S, typename T>
 __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
     typedef NarrowWCfg<CIN, COUT, S> C;
+    typedef NarrowIO<T> IO;
     constexpr int TH = C::TH, TW = C::TW, IH = C::IH, IW = C::IW, PLANE = C::PLANE, ROWPX = C::ROWPX;
     constexpr int QX = C::QX, QD = C::QD, NB = C::NB, RG = C::RG, NX = C::NX, ND = C::ND;
     constexpr int GPR = TW / 4, NGRP = TH * GPR / 4;                   // 4-pixel groups per row / per wave
@@ -342,20 +380,20 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
         const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
         const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-        const float *xb = g.x + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldx;
-        const float *db = g.dy + ((ptrdiff_t)(b * g.Ho + oy0) * g.Wo + ox0) * g.lddy;
+        const T *xb = (const T *)g.x + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldx;
+        const T *db = (const T *)g.dy + ((ptrdiff_t)(b * g.Ho + oy0) * g.Wo + ox0) * g.lddy;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = *(const f32x4 *)(xb + gx[k]);
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = IO::load4(xb + gx[k]);
             rx[k] = v;
         }
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             const int oy = oy0 + (int)((md[k] >> 16) & 255u), ox = ox0 + (int)(md[k] >> 24);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < g.Ho && ox < g.Wo) v = *(const f32x4 *)(db + gd[k]);
+            if (oy < g.Ho && ox < g.Wo) v = IO::load4(db + gd[k]);
             rd[k] = v;
         }
     };
@@ -481,14 +519,14 @@ int narrow_wgrad_grid(int npatch, int Cin) {
     return npatch < target ? npatch : target;
 }
 
-template <int CIN, int COUT, int S>
+template <int CIN, int COUT, int S, typename T>
 int narrow_wgrad_launch(NarrowW g, float *dw, int cin_real, hipStream_t st) {
     typedef NarrowWCfg<CIN, COUT, S> C;
     g.tiles_x = cdiv(g.Wo, C::TW);
     g.tiles_y = cdiv(g.Ho, C::TH);
     g.npatch = g.B * g.tiles_x * g.tiles_y;
     const int grid = narrow_wgrad_grid(g.npatch, CIN);
-    hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S>), dim3(grid), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S, T>), dim3(grid), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow_bwd_weight");
     hipLaunchKernelGGL((narrow_wgrad_reduce_kernel<CIN, COUT>), dim3(cdiv(COUT * cin_real * 9, 16)), dim3(256), 0, st, g.ws, dw, grid,
                        cin_real);
@@ -527,42 +565,67 @@ extern "C" int yh_conv_narrow_blocks(int B, int Hi, int Wi, int Cin, int s) {
 
 extern "C" int yh_conv_narrow_dgrad_s2_ok(int Cin, int Cout) { return Cin == 16 && Cout == 32 ? 1 : 0; }
 
-extern "C" int yh_conv_narrow_dgrad_s2(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi, int Wi,
-                                       int Cin, int Cout, int accumulate, void *stream) {
+template <typename T>
+static int narrow_dgrad_s2_t(const T *dy, int lddy, const T *wb, int ldwb, int kpad, T *dx, int lddx, int B, int Hi, int Wi, int Cin, int Cout,
+                             int accumulate, void *stream) {
     YH_REQUIRE(dy && wb && dx && B > 0 && Hi > 0 && Wi > 0, "conv_narrow_dgrad_s2: bad argument");
     YH_REQUIRE(yh_conv_narrow_dgrad_s2_ok(Cin, Cout), "conv_narrow_dgrad_s2: unsupported shape %d <- %d", Cin, Cout);
-    YH_REQUIRE(lddy >= Cout && lddy % 4 == 0 && ((uintptr_t)dy & 15) == 0 && lddx >= Cin && ldwb >= Cin, "conv_narrow_dgrad_s2: views must be 16-byte addressable");
+    YH_REQUIRE(lddy >= Cout && lddy % 4 == 0 && ((uintptr_t)dy & (4 * sizeof(T) - 1)) == 0 && lddx >= Cin && ldwb >= Cin,
+               "conv_narrow_dgrad_s2: views must be addressable in 4-channel pieces");
     Narrow g{};
-    g.in = dy; g.w = wb; g.out = dx; g.ldi = lddy; g.ldw = ldwb; g.ldo = lddx; g.B = B;
+    g.in = dy; g.w = wb; g.out = dx; g.ldi = lddy; g.ldw = ldwb; g.ldo = lddx; g.B = B; g.kpad = kpad;
     g.Ho = Hi; g.Wo = Wi;                                  // dX
     g.Hi = (Hi - 1) / 2 + 1; g.Wi = (Wi - 1) / 2 + 1;      // dY
     g.accumulate = accumulate ? 1 : 0;
     g.tiles_x = cdiv(Wi, 64); g.tiles_y = cdiv(Hi, 8);
-    hipLaunchKernelGGL((narrow_dgrad_s2_kernel<32, 16>), dim3(B * g.tiles_x * g.tiles_y), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((narrow_dgrad_s2_kernel<32, 16, T>), dim3(B * g.tiles_x * g.tiles_y), dim3(256), 0, (hipStream_t)stream, g);
     YH_CHECK_LAUNCH("conv_narrow_dgrad_s2");
     return 0;
 }
+extern "C" int yh_conv_narrow_dgrad_s2(const float *dy, int lddy, const float *wb, int ldwb, float *dx, int lddx, int B, int Hi, int Wi,
+                                       int Cin, int Cout, int accumulate, void *stream) {
+    return narrow_dgrad_s2_t<float>(dy, lddy, wb, ldwb, 0, dx, lddx, B, Hi, Wi, Cin, Cout, accumulate, stream);
+}
+extern "C" int yh_bf16_conv_narrow_dgrad_s2(const void *dy, int lddy, const void *wb, int ldwb, int kpad, void *dx, int lddx, int B, int Hi,
+                                            int Wi, int Cin, int Cout, int accumulate, void *stream) {
+    YH_REQUIRE(kpad >= Cout && kpad % 8 == 0, "bf16_conv_narrow_dgrad_s2: bad pack padding");
+    return narrow_dgrad_s2_t<nbf16>((const nbf16 *)dy, lddy, (const nbf16 *)wb, ldwb, kpad, (nbf16 *)dx, lddx, B, Hi, Wi, Cin, Cout, accumulate,
+                                    stream);
+}
 
-extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy,
-                              float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate,
-                              void *stream) {
+template <typename T>
+static int narrow_conv_t(const T *x, int ldx, const T *w, int ldw, int kpad, const float *bias, T *y, int ldy, float *bn_partials, int B,
+                         int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream) {
     YH_REQUIRE(x && w && y && B > 0 && Hi > 0 && Wi > 0, "conv_narrow: bad argument");
     YH_REQUIRE(yh_conv_narrow_ok(Cin, Cout, 3, s), "conv_narrow: unsupported shape %d -> %d stride %d", Cin, Cout, s);
-    YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ldy >= Cout && ldw >= Cout, "conv_narrow: views must be 16-byte addressable");
+    YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & (4 * sizeof(T) - 1)) == 0 && ldy >= Cout && ldw >= Cout,
+               "conv_narrow: views must be addressable in 4-channel pieces");
     YH_REQUIRE(!(flip_taps && s != 1), "conv_narrow: flipped taps (backward-data) only for stride 1");
     Narrow g{};
-    g.in = x; g.w = w; g.bias = bias; g.out = y; g.stats = bn_partials;
+    g.in = x; g.w = w; g.bias = bias; g.out = y; g.stats = bn_partials; g.kpad = kpad;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.B = B; g.Hi = Hi; g.Wi = Wi;
     g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
     g.flip = flip_taps ? 1 : 0; g.accumulate = accumulate ? 1 : 0;
     const int nt = narrow_tiles(g.Ho, g.Wo, Cin, s, g.tiles_x, g.tiles_y);
     hipStream_t st = (hipStream_t)stream;
     const int grid = narrow_conv_grid(B * nt);
-    if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1>), dim3(grid), dim3(256), 0, st, g);
-    else if (Cin == 4) hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2>), dim3(grid), dim3(256), 0, st, g);
+    if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1, T>), dim3(grid), dim3(256), 0, st, g);
+    else if (Cin == 4) hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2, T>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2, T>), dim3(grid), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow");
     return 0;
+}
+extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy,
+                              float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate,
+                              void *stream) {
+    return narrow_conv_t<float>(x, ldx, w, ldw, 0, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, s, flip_taps, accumulate, stream);
+}
+extern "C" int yh_bf16_conv_narrow(const void *x, int ldx, const void *w, int ldw, int kpad, const float *bias, void *y, int ldy,
+                                   float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate,
+                                   void *stream) {
+    YH_REQUIRE(kpad >= Cin && kpad % 8 == 0, "bf16_conv_narrow: bad pack padding");
+    return narrow_conv_t<nbf16>((const nbf16 *)x, ldx, (const nbf16 *)w, ldw, kpad, bias, (nbf16 *)y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, s,
+                                flip_taps, accumulate, stream);
 }
 
 extern "C" int yh_conv_narrow_bwd_weight_ok(int Cin, int cin_real, int Cout, int k, int s) {
@@ -581,19 +644,30 @@ extern "C" int64_t yh_conv_narrow_bwd_weight_ws(int B, int Hi, int Wi, int Cin, 
     return (int64_t)narrow_wgrad_grid((int)(npatch < (1 << 30) ? npatch : (1 << 30)), Cin) * slab;
 }
 
-extern "C" int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
-                                         int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
+template <typename T>
+static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float *dw, float *ws, int64_t ws_floats, int B, int Hi, int Wi,
+                               int Cin, int cin_real, int Cout, int s, void *stream) {
     YH_REQUIRE(x && dy && dw && ws && B > 0 && Hi > 0 && Wi > 0, "conv_narrow_bwd_weight: bad argument");
     YH_REQUIRE(yh_conv_narrow_bwd_weight_ok(Cin, cin_real, Cout, 3, s), "conv_narrow_bwd_weight: unsupported shape %d(%d) -> %d stride %d",
                Cin, cin_real, Cout, s);
-    YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && lddy >= Cout && lddy % 4 == 0 && ((uintptr_t)dy & 15) == 0,
-               "conv_narrow_bwd_weight: views must be 16-byte addressable");
+    YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & (4 * sizeof(T) - 1)) == 0 && lddy >= Cout && lddy % 4 == 0 &&
+                   ((uintptr_t)dy & (4 * sizeof(T) - 1)) == 0,
+               "conv_narrow_bwd_weight: views must be addressable in 4-channel pieces");
     YH_REQUIRE(ws_floats >= yh_conv_narrow_bwd_weight_ws(B, Hi, Wi, Cin, Cout, s), "conv_narrow_bwd_weight: workspace too small");
     NarrowW g{};
     g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy; g.B = B; g.Hi = Hi; g.Wi = Wi;
     g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (Cin == 16 && s == 1) return narrow_wgrad_launch<16, 16, 1>(g, dw, cin_real, st);
-    if (Cin == 16) return narrow_wgrad_launch<16, 32, 2>(g, dw, cin_real, st);
-    return narrow_wgrad_launch<4, 16, 2>(g, dw, cin_real, st);
+    if (Cin == 16 && s == 1) return narrow_wgrad_launch<16, 16, 1, T>(g, dw, cin_real, st);
+    if (Cin == 16) return narrow_wgrad_launch<16, 32, 2, T>(g, dw, cin_real, st);
+    return narrow_wgrad_launch<4, 16, 2, T>(g, dw, cin_real, st);
+}
+extern "C" int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                                         int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
+    return narrow_bwd_weight_t<float>(x, ldx, dy, lddy, dw, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s, stream);
+}
+extern "C" int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
+                                              int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
+    return narrow_bwd_weight_t<nbf16>((const nbf16 *)x, ldx, (const nbf16 *)dy, lddy, dw, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s,
+                                      stream);
 }

@@ -118,6 +118,7 @@ class ConvRec:
     narrow_f: bool = False  # forward on the direct kernel for the narrow high-resolution 3x3 layers
     narrow_b: bool = False  # stride-1 backward-data on the same kernel (flipped taps)
     narrow_w: bool = False  # weight gradient on the direct pixel-reduction kernel
+    cin_k: int = 0          # bf16 plan: input channels the narrow kernels read (4 of the first layer's 8 padded ones)
     fwd2: bool = False      # forward fused with the sibling pointwise conv (one GEMM, N = cout1 + cout2)
     nblk: int = 0           # BatchNorm partial-sum rows written by the forward kernel
     pw_b: bool = False      # backward-data on the pointwise GEMM kernel
@@ -560,12 +561,34 @@ class Plan:
                           r.cin, r.ldwf, r.ldwb, koff, kpad))
             M = r.x.B * r.Ho * r.Wo
             r.nblk = lib.yh_bf16_conv_blocks(M)
+            # narrow high-resolution 3x3 layers (first layer, stem[3], the 16-channel bottleneck): the direct kernels of the fp32
+            # path with bf16 storage (conv_narrow.hip); cin_k = channels the kernel reads (4 of the first layer's 8 padded ones)
+            use_nar = os.environ.get("YH_BF16_NARROW", "1") != "0" and r.k == 3 and r.bn is not None and r.x.ld % 4 == 0 and r.x.off % 4 == 0
+            r.cin_k = 4 if (cin_real <= 4 and r.cin == 8) else r.cin
+            # measured at batch 64 (tools/layer_bench.py --dtype bf16, ms narrow / generic bf16): first layer forward 0.250 /
+            # 0.358 and weight gradient 0.220 / 0.541; stem[3] forward 0.250 / 0.114, backward-data 0.295 / 0.338, weight gradient
+            # 0.274 / 0.155; 16 -> 16 forward 0.098 / 0.098, backward-data 0.114 / 0.099, weight gradient 0.113 / 0.129 per layer
+            # (8-byte pieces: twice the load instructions per byte of the fp32 form -- these kernels are bound by instruction
+            # issue and latency, not by bytes).  Each pass takes the faster kernel; YH_BF16_NARROW=all forces the narrow ones.
+            every = os.environ.get("YH_BF16_NARROW", "1") == "all"
+            r.narrow_f = bool(use_nar and (r.cin_k == 4 or (every and r.cin == cin_real)) and lib.yh_conv_narrow_ok(r.cin_k, r.cout, 3, r.s))
+            r.narrow_w = bool(use_nar and (r.cin_k == 4 or r.s == 1 or every) and
+                              lib.yh_conv_narrow_bwd_weight_ok(r.cin_k, min(cin_real, r.cin_k), r.cout, 3, r.s))
+            r.narrow_b = bool(use_nar and r.need_dx and r.pair is None and r.cin == cin_real and
+                              ((r.s == 1 and every and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1)) or
+                               (r.s == 2 and lib.yh_conv_narrow_dgrad_s2_ok(r.cin, r.cout))))
+            if r.narrow_f:
+                r.nblk = lib.yh_conv_narrow_blocks(r.x.B, r.x.H, r.x.W, r.cin_k, r.s)
             if r.bn is not None:
                 r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **b16)
                 r.coef = torch.empty(4 * r.cout, **f32)
                 r.part = torch.empty(max(r.nblk, lib.yh_bn_bwd_blocks(M, r.cout)) * 2 * r.cout, **f32)
-                fwd.append(_op(L.OP_BF16_CONV_FWD, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part],
-                               i=[r.x.ld, r.ldwf, r.cout, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, 0], lane=ln))
+                if r.narrow_f:
+                    fwd.append(_op(L.OP_BF16_CONV_NARROW, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part],
+                                   i=[r.x.ld, r.ldwf, r.cout, r.x.B, r.x.H, r.x.W, r.cin_k, r.cout, r.s, 0, 0, r.cin], lane=ln))
+                else:
+                    fwd.append(_op(L.OP_BF16_CONV_FWD, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part],
+                                   i=[r.x.ld, r.ldwf, r.cout, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, 0], lane=ln))
                 track = r.bn.track_running_stats and r.bn.running_mean is not None
                 mom = r.bn.momentum if r.bn.momentum is not None else 0.1
                 fwd.append(_op(L.OP_BN_FINALIZE,
@@ -599,7 +622,8 @@ class Plan:
         ws_floats = 1
         for r in self.recs:
             if isinstance(r, ConvRec):
-                ws_floats = max(ws_floats, lib.yh_bf16_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
+                ws_floats = max(ws_floats, lib.yh_conv_narrow_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin_k, r.cout, r.s) if r.narrow_w else
+                                lib.yh_bf16_conv_bwd_weight_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
                 if r.bias is not None:
                     ws_floats = max(ws_floats, lib.yh_colsum_ws(r.x.B * r.Ho * r.Wo, r.cout))
         self.ws = torch.empty(int(ws_floats), device=self.device, dtype=torch.float32)
@@ -641,8 +665,13 @@ class Plan:
                 cs = _rup4(r.cout) if (r.bn is None and _rup4(r.cout) <= lddy) else r.cout
                 ops.append(_op(L.OP_BF16_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, cs], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
-            ops.append(_op(L.OP_BF16_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
-                           i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s], l=[self.ws.numel()]))
+            if r.narrow_w:
+                ops.append(_op(L.OP_BF16_CONV_NARROW_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+                               i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin_k, min(r.weight.shape[1], r.cin_k), r.cout, r.k, r.s],
+                               l=[self.ws.numel()]))
+            else:
+                ops.append(_op(L.OP_BF16_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+                               i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s], l=[self.ws.numel()]))
             self.grad_ready[id(r.weight)] = len(ops)
             if not r.need_dx:
                 continue
@@ -657,8 +686,15 @@ class Plan:
                     pair_pending.add(id(r))
                 continue
             dst, acc = self._grad_target(r.x)
-            ops.append(_op(L.OP_BF16_CONV_BWD_DATA, p=[dy, r.wb, dst, None],
-                           i=[lddy, r.ldwb, r.x.ldg, r.x.B, r.x.H, r.x.W, r.cin, kcout, r.k, r.s, acc, 0]))
+            if r.narrow_b and r.s == 1:      # x = dY (Cout channels), output = dX (Cin channels), backward pack, flipped taps
+                ops.append(_op(L.OP_BF16_CONV_NARROW, p=[dy, r.wb, None, dst, None],
+                               i=[lddy, r.ldwb, r.x.ldg, r.x.B, r.x.H, r.x.W, r.cout, r.cin, 1, 1, acc, _rup8(r.cout)]))
+            elif r.narrow_b:
+                ops.append(_op(L.OP_BF16_CONV_NARROW_DGRAD_S2, p=[dy, r.wb, dst],
+                               i=[lddy, r.ldwb, r.x.ldg, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc, _rup8(r.cout)]))
+            else:
+                ops.append(_op(L.OP_BF16_CONV_BWD_DATA, p=[dy, r.wb, dst, None],
+                               i=[lddy, r.ldwb, r.x.ldg, r.x.B, r.x.H, r.x.W, r.cin, kcout, r.k, r.s, acc, 0]))
         return ops
 
     def _grad_target(self, v: View) -> Tuple[int, int]:
