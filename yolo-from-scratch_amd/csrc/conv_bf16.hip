@@ -16,6 +16,11 @@
 // MFMA operand maps (cdna guide section 3): v_mfma_f32_32x32x16_bf16, lane l (r = l & 31, h = l >> 5) holds
 // A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7; D register q of lane l = D[(q & 3) + 8 (q >> 2) + 4h][col r].
 #include "common.h"
+#ifdef YH_BF_STAMPS
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -47,6 +52,9 @@ struct BfGemm {
     unsigned cin_magic, xo_magic, yo_magic;
     int xo_shift, yo_shift;
     int tap_dy[9], tap_dx[9], tap_w[9];
+#ifdef YH_BF_STAMPS
+    unsigned long long *dbg;
+#endif
 };
 struct BfGemmSet {
     BfGemm c[4];
@@ -77,6 +85,9 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     unsigned char *Bs = smem + 2 * BM * A_STRIDE;          // [2][8][BN][16]
     int *tapt = (int *)(Bs + 2 * 8 * BN * 16);             // [3][9]
 
+#ifdef YH_BF_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
@@ -192,6 +203,9 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+#ifdef YH_BF_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     const int nchunks = (g.Ktot + BK - 1) / BK;
     auto compute = [&](int buf, int kvalid) {
         const unsigned char *a = As + buf * BM * A_STRIDE + (wm * TM * 32 + lr) * A_STRIDE + 16 * lh;
@@ -228,6 +242,9 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
         __syncthreads();
     }
 
+#ifdef YH_BF_STAMPS
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue --------------------------------------------------------------------------------------------------
     float bias_v[TN];
 #pragma unroll
@@ -339,6 +356,12 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
             g.stats[((size_t)mblk * 2 + 1) * g.N + n0 + t] = q;
         }
     }
+#ifdef YH_BF_STAMPS
+    if (g.dbg && t == 0 && (NCLS == 1 || blockIdx.y == 0)) {
+        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 void set_magic(unsigned d, unsigned &magic, int &shift) {
@@ -376,8 +399,32 @@ int launch_cfg2(BfGemmSet &gs, hipStream_t st) {
         int blk = cdiv(g.M, BM) * g.nblk_n;
         if (blk > maxblk) maxblk = blk;
     }
+#ifdef YH_BF_STAMPS
+    static unsigned long long *dbgbuf = nullptr;
+    if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
+    const bool dbg_on = getenv("YH_BF_DBG") && (size_t)maxblk * 48 <= ((size_t)1 << 24);
+    for (int c = 0; c < NCLS; ++c) gs.c[c].dbg = dbg_on ? dbgbuf : nullptr;
+#endif
     hipLaunchKernelGGL(kern, dim3(maxblk, NCLS), dim3(256), smem, st, gs);
     YH_CHECK_LAUNCH("bf16_gemm");
+#ifdef YH_BF_STAMPS
+    if (dbg_on) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)maxblk * 6);
+        (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        double a = 0, b = 0, c2 = 0, rt = 0; unsigned long long lo = ~0ull, hi = 0;
+        for (int i = 0; i < maxblk; ++i) {
+            a += (double)(h[6 * i + 1] - h[6 * i]); b += (double)(h[6 * i + 2] - h[6 * i + 1]); c2 += (double)(h[6 * i + 3] - h[6 * i + 2]);
+            rt += (double)(h[6 * i + 5] - h[6 * i + 4]);
+            if (h[6 * i + 4] < lo) lo = h[6 * i + 4];
+            if (h[6 * i + 5] > hi) hi = h[6 * i + 5];
+        }
+        const BfGemm &g0 = gs.c[0];
+        const double mf = (double)((g0.Ktot + 63) / 64) * (BM / WM / 32) * (BN / WN / 32) * 4 * 32.4;
+        fprintf(stderr, "[bf16 stamps] BM %d BN %d NCLS %d M %d N %d K %d wgs %d: setup %.0f, loop %.0f (MFMA issue floor %.0f), epilogue %.0f cycles = %.2f us per workgroup (clock %.2f GHz); span %.1f us\n",
+                BM, BN, NCLS, g0.M, g0.N, g0.Ktot, maxblk, a / maxblk, b / maxblk, mf, c2 / maxblk, rt / maxblk / 100.0, (a + b + c2) / rt * 0.1, (double)(hi - lo) / 100.0);
+    }
+#endif
     return 0;
 }
 
