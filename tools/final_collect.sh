@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/final_collect.sh -- the stamped step profiles (fp32 + bf16), the serial kernel table and the
+# headline bench line, all for the tree as it stands (run after the LAST change under csrc/: bench.py quotes the PMC traffic only
+# when the profile's stamp equals the tree's hash).  Outputs land in gpurun_out/; copy them with tools/store_evidence.py.
+set -e
+bash tools/collect_step_profile.sh f32
+python tools/step_profile.py gpurun_out/sp_f32_trace/t_results.db gpurun_out/sp_f32_fetch/c_results.db gpurun_out/sp_f32_write/c_results.db profiles/r02_step_profile_f32.json > gpurun_out/sp_f32.log 2>&1
+python tools/kernel_stats.py gpurun_out/sp_f32_trace/t_results.db profiles/r02_kernel_stats_f32_serial.csv --per-step 5 > /dev/null 2>&1
+bash tools/collect_step_profile.sh bf16 YH_BENCH_DTYPE=bf16 YH_BENCH_SHAPE=80,640,64
+python tools/step_profile.py gpurun_out/sp_bf16_trace/t_results.db gpurun_out/sp_bf16_fetch/c_results.db gpurun_out/sp_bf16_write/c_results.db profiles/r02_step_profile_bf16.json > gpurun_out/sp_bf16.log 2>&1
+cp profiles/r02_step_profile_f32.json profiles/r02_step_profile_bf16.json profiles/r02_kernel_stats_f32_serial.csv gpurun_out/
+python bench.py > gpurun_out/ev_bench_f32.json 2> gpurun_out/ev_bench_f32.err
+echo final2
