@@ -35,6 +35,7 @@ struct GatherGemm {
     int sy, sx;
     int nTaps, Ktot;
     int accumulate, dense;
+    int off32;            // every output element offset fits 31 bits (set by the launcher)
     const float *res;     // inference epilogue: + residual (after the activation), ld = ldr
     int ldr, act, up2;    // act: 1 = SiLU on (acc + bias); up2: replicate each output pixel 2x2 (nearest upsample)
     int nblk_n;
@@ -331,6 +332,76 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
         int n = n0 + wn * TN * MT + j * MT + lr;
         bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
     }
+    if (MT == 32 && !(g.act | g.up2 | (g.res != nullptr)) && g.off32) {
+        // training form.  The output pixel of each of the tile's BM rows is computed ONCE (one thread per row, two divisions for
+        // a strided output lattice) and parked in LDS; a lane then reads its 16 TM rows' offsets with 16-byte LDS reads instead
+        // of dividing 16 TM times, and a whole tile (every row and column valid) stores without per-element tests -- on the
+        // one-tap parity class of a stride-2 backward-data pass the tested epilogue cost more than the 32-MFMA main loop.
+        int *orow = (int *)(smem + 2 * WM * BN);                          // behind the partial-sum exchange area
+        if (t < BM) {
+            const int m = m0 + t;
+            int op = -1;
+            if (m < g.M) {
+                if (g.dense) {
+                    op = m;
+                } else {
+                    int q = fast_div(m, g.xo_magic, g.xo_shift), x = m - q * g.Xo;
+                    int b = fast_div(q, g.yo_magic, g.yo_shift), y = q - b * g.Yo;
+                    op = (b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
+                }
+            }
+            orow[t] = op;
+        }
+        __syncthreads();
+        const bool whole = m0 + BM <= g.M && n0 + BN <= g.N;              // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int op[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i32x4 v = *(const i32x4 *)(orow + wm * TM * MT + i * MT + 8 * q + 4 * lh);
+                op[4 * q] = v[0]; op[4 * q + 1] = v[1]; op[4 * q + 2] = v[2]; op[4 * q + 3] = v[3];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * TN * MT + j * MT + lr;
+                if (whole) {
+                    if (!g.accumulate) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[i][j][r] + bias_v[j];
+                            g.out[(unsigned)(op[r] * g.ldo + n)] = v;
+                            csum[j] += v;
+                            csq[j] += v * v;
+                        }
+                    } else {
+                        float old[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) old[r] = g.out[(unsigned)(op[r] * g.ldo + n)];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[i][j][r] + bias_v[j] + old[r];
+                            g.out[(unsigned)(op[r] * g.ldo + n)] = v;
+                            csum[j] += v;
+                            csq[j] += v * v;
+                        }
+                    }
+                } else if (n < g.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (op[r] >= 0) {
+                            float *o = g.out + (unsigned)(op[r] * g.ldo + n);
+                            float v = acc[i][j][r] + bias_v[j];
+                            if (g.accumulate) v += *o;
+                            *o = v;
+                            csum[j] += v;
+                            csq[j] += v * v;
+                        }
+                }
+            }
+        }
+        __syncthreads();                                                   // orow is consumed before the partial sums reuse LDS
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -416,6 +487,7 @@ int launch_cfg(GatherGemmSet gs, hipStream_t st) {
         GatherGemm &g = gs.c[c];
         g.nblk_n = cdiv(g.N, BN);
         g.cin_magic = (unsigned)((1ull << 32) / (unsigned)g.Cin) + 1u;
+        g.off32 = (int64_t)g.B * g.Ho_f * g.Wo_f * g.ldo < (1ll << 31) ? 1 : 0;
         int blk = cdiv(g.M, BM) * g.nblk_n;
         if (blk > maxblk) maxblk = blk;
     }
