@@ -291,7 +291,15 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
                             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)q * PH * PW * 4], bw[(kh * 3 + kw) * Q + q], acc, 0, 0, 0);
                     }
                 }
-                if (y < g.Ho) {
+                if (y0 + TH <= g.Ho && x0 + TW <= g.Wo) {      // whole patch (workgroup-uniform): no per-element tests
+                    T *o = gout + ((size_t)(b * g.Ho + y) * g.Wo + x0 + 2 * (16 * seg + 4 * kk) + pxp) * g.ldo + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[r];
+                        if (g.accumulate) v += IO::load1(o + (size_t)(2 * r) * g.ldo);
+                        IO::store1(o + (size_t)(2 * r) * g.ldo, v);
+                    }
+                } else if (y < g.Ho) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int x = x0 + 2 * (16 * seg + 4 * kk + r) + pxp;
