@@ -151,12 +151,13 @@ int yh_conv_narrow_dgrad_s2(const float *dy, int lddy, const float *wb, int ldwb
  * takes 4 consecutive output pixels as k, the 16 rows are the input channels of one tap (or 4 taps x 4 channels), the
  * columns 16 output channels; persistent workgroups keep all accumulator tiles in registers and write one slab each, summed
  * in fixed order (bitwise reproducible).  Every x and dY element is read from HBM once.  Writes OIHW; same result as
- * yh_conv_bwd_weight(k = 3).  ws_floats >= yh_conv_narrow_bwd_weight_ws(...).  replaces: aten::convolution_backward (weight
+ * yh_conv_bwd_weight(k = 3).  dbias != NULL: also the conv's bias gradient (column sums of dY: the pieces pass through the
+ * kernel's registers anyway, which saves the separate yh_colsum pass over dY).  ws_floats >= yh_conv_narrow_bwd_weight_ws(...).  replaces: aten::convolution_backward (weight
  * gradient) of stem[0], stem[3] and the 1/4-resolution Bottleneck convs, train.py:913. */
 int yh_conv_narrow_bwd_weight_ok(int Cin, int cin_real, int Cout, int k, int s);
 int64_t yh_conv_narrow_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int s);
-int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats, int B,
-                              int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
+int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *dbias, float *ws, int64_t ws_floats,
+                              int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
 /* The narrow-layer kernels with bf16 storage (bf16 path, BASELINE configs 3-4): activations, activation gradients and the
  * weight packs of yh_bf16_pack_multi ([tap][kpad / 8][ld][8]) are bf16 in HBM; they are widened when parked in LDS and the fp32
  * MFMA loop of the fp32 kernels runs unchanged (these layers are bound by HBM bytes and latency, products of bf16 values are
@@ -167,8 +168,8 @@ int yh_bf16_conv_narrow(const void *x, int ldx, const void *w, int ldw, int kpad
                         int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream);
 int yh_bf16_conv_narrow_dgrad_s2(const void *dy, int lddy, const void *wb, int ldwb, int kpad, void *dx, int lddx, int B, int Hi, int Wi,
                                  int Cin, int Cout, int accumulate, void *stream);
-int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *ws, int64_t ws_floats, int B, int Hi,
-                                   int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
+int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *dbias, float *ws, int64_t ws_floats,
+                                   int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
 /* Winograd F(2x2,3x3) path for 3x3 / stride-1 / pad-1 convolutions with even H, W and K % 16 == 0 (K = Cin forward,
  * Cout backward): the same results as yh_conv_fwd / yh_conv_bwd_data to fp32 rounding with 4/9 of the multiplies.
  * yh_wino_weights transforms OIHW weights into U[16][K][ldu] (backward = 0: K = Cin, N = Cout; backward = 1: the
@@ -433,10 +434,10 @@ enum {
     YH_OP_FOLD_OIHW_MULTI, YH_OP_CONV_WINO_FWD_FUSED, YH_OP_CONV_PW_FWD_FUSED,  /* slots of YH_OP_CONV_FWD_FUSED */
     YH_OP_CONV_NARROW,  /* p: x, w, bias, y, partials;  i: ldx, ldw, ldy, B, H, W, Cin, Cout, s, flip_taps, accumulate */
     YH_OP_CONV_NARROW_DGRAD_S2,  /* slots of YH_OP_CONV_BWD_DATA */
-    YH_OP_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT */
+    YH_OP_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
     YH_OP_BF16_CONV_NARROW,       /* slots of YH_OP_CONV_NARROW + i[11] = kpad (padded K rows per tap of the bf16 pack) */
     YH_OP_BF16_CONV_NARROW_DGRAD_S2,   /* slots of YH_OP_CONV_BWD_DATA + i[11] = kpad */
-    YH_OP_BF16_CONV_NARROW_BWD_WEIGHT  /* slots of YH_OP_CONV_BWD_WEIGHT */
+    YH_OP_BF16_CONV_NARROW_BWD_WEIGHT  /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

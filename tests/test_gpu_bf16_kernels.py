@@ -409,9 +409,11 @@ def test_bf16_narrow_layer_kernels(B, H, W, Cin, Cout, s):
     nws = int(lib.yh_conv_narrow_bwd_weight_ws(B, H, W, cin_k, Cout, s))
     ws = torch.empty(nws, device="cuda")
     dw = torch.full((Cout, Cin, 3, 3), 9.0, device="cuda")
+    db = torch.full((Cout,), 9.0, device="cuda")
     args = (xv.data_ptr(), cin + 8, dyg.data_ptr(), kp)
-    L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw.data_ptr(), ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
+    L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
     assert rel_err(dw, want_dw) < F32_OUT_TOL
+    assert rel_err(db, dy.double().sum((0, 2, 3))) < F32_OUT_TOL
     dw2 = torch.empty_like(dw)
-    L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw2.data_ptr(), ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
+    L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw2.data_ptr(), None, ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
     assert torch.equal(dw, dw2)

@@ -484,15 +484,17 @@ def test_narrow_weight_gradient_kernel(B, H, W, Cin, creal, Cout, s):
     nws = lib.yh_conv_narrow_bwd_weight_ws(B, H, W, Cin, Cout, s)
     ws = torch.full((nws,), float("nan"), device="cuda")
     dw = torch.full((Cout, creal, 3, 3), 7.0, device="cuda")
+    db = torch.full((Cout,), 7.0, device="cuda")                          # bias gradient = column sums of dY, from the same launch
     args = (xv.data_ptr(), ldx, dv.data_ptr(), lddy)
-    L.check(lib.yh_conv_narrow_bwd_weight(*args, dw.data_ptr(), ws.data_ptr(), nws, B, H, W, Cin, creal, Cout, s, st), "narrow wgrad")
+    L.check(lib.yh_conv_narrow_bwd_weight(*args, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, Cin, creal, Cout, s, st), "narrow wgrad")
     assert rel_err(dw, want) < 1e-5
+    assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5
     dw2 = torch.empty_like(dw)
-    L.check(lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), ws.data_ptr(), nws, B, H, W, Cin, creal, Cout, s, st), "narrow wgrad")
+    L.check(lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), None, ws.data_ptr(), nws, B, H, W, Cin, creal, Cout, s, st), "narrow wgrad")
     assert torch.equal(dw, dw2)
     nws_g = lib.yh_conv_bwd_weight_ws(B, H, W, Cin, Cout, 3, s)
     ws_g = torch.empty(nws_g, device="cuda")
     dw3 = torch.empty_like(dw)
     L.check(lib.yh_conv_bwd_weight(*args, dw3.data_ptr(), ws_g.data_ptr(), nws_g, B, H, W, Cin, creal, Cout, 3, s, st), "generic wgrad")
     assert rel_err(dw, dw3) < 1e-5
-    assert lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), ws.data_ptr(), nws - 1, B, H, W, Cin, creal, Cout, s, st) != 0
+    assert lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), None, ws.data_ptr(), nws - 1, B, H, W, Cin, creal, Cout, s, st) != 0

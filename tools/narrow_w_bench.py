@@ -28,7 +28,7 @@ def main():
         dw = torch.empty(Cout, creal, 3, 3, device="cuda")
 
         def run():
-            L.check(lib.yh_conv_narrow_bwd_weight(x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), ws.data_ptr(), nws, B, H, W, Cin,
+            L.check(lib.yh_conv_narrow_bwd_weight(x.data_ptr(), Cin, dy.data_ptr(), Cout, dw.data_ptr(), None, ws.data_ptr(), nws, B, H, W, Cin,
                                                   creal, Cout, s, st))
         for _ in range(3):
             run()

@@ -75,9 +75,9 @@ _SIGS = {
     "yh_conv_narrow_bwd_weight_ok": (i32, [i32, i32, i32, i32, i32]),
     "yh_bf16_conv_narrow": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_bf16_conv_narrow_dgrad_s2": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
-    "yh_bf16_conv_narrow_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_narrow_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_narrow_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32]),
-    "yh_conv_narrow_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_narrow_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_narrow_dgrad_s2": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_narrow": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pw_pack_multi": (i32, [c_fp, i32, c_fp]),

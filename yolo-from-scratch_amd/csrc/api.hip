@@ -115,7 +115,7 @@ static int run_one(const yh_op &o, void *st) {
             return yh_conv_narrow_dgrad_s2((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4], i[5],
                                            i[6], i[7], i[10], st);
         case YH_OP_CONV_NARROW_BWD_WEIGHT:  /* same argument slots as YH_OP_CONV_BWD_WEIGHT (k = 3 implied) */
-            return yh_conv_narrow_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
+            return yh_conv_narrow_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[4], (float *)p[3],
                                              o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[9], st);
         case YH_OP_BF16_CONV_NARROW:
             return yh_bf16_conv_narrow(p[0], i[0], p[1], i[1], i[11], (const float *)p[2], p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6],
@@ -123,8 +123,8 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_BF16_CONV_NARROW_DGRAD_S2:
             return yh_bf16_conv_narrow_dgrad_s2(p[0], i[0], p[1], i[1], i[11], p[2], i[2], i[3], i[4], i[5], i[6], i[7], i[10], st);
         case YH_OP_BF16_CONV_NARROW_BWD_WEIGHT:
-            return yh_bf16_conv_narrow_bwd_weight(p[0], i[0], p[1], i[1], (float *)p[2], (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], i[6],
-                                                  i[7], i[9], st);
+            return yh_bf16_conv_narrow_bwd_weight(p[0], i[0], p[1], i[1], (float *)p[2], (float *)p[4], (float *)p[3], o.l[0], i[2], i[3], i[4],
+                                                  i[5], i[6], i[7], i[9], st);
         case YH_OP_FOLD_OIHW_MULTI:
             return yh_fold_oihw_multi(p[0], i[0], st);
         case YH_OP_CONV_WINO_FWD_FUSED:     /* slots of YH_OP_CONV_FWD_FUSED (k = 3, s = 1 implied) */

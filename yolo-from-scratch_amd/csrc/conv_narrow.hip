@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
 struct NarrowW {
     const void *x, *dy;
     float *ws;
+    float *bws;                   // != NULL: per-workgroup column sums of dY (the conv's bias gradient), [grid][COUT]
     int ldx, lddy;
     int B, Hi, Wi, Ho, Wo;
     int tiles_x, tiles_y, npatch;
@@ -430,11 +431,16 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
     for (int r = 0; r < RG; ++r)
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     int pid = blockIdx.x;
     if (pid < g.npatch) fetch(pid);
     for (; pid < g.npatch; pid += gridDim.x) {
         __syncthreads();                                               // the previous patch's fragments are consumed
+        if (g.bws) {                                                   // bias gradient: this thread's dY pieces all carry channel quad t % QD
+#pragma unroll
+            for (int k = 0; k < ND; ++k) bsum += rd[k];
+        }
         park();
         __syncthreads();
         if (pid + (int)gridDim.x < g.npatch) fetch(pid + gridDim.x);   // in flight under the MFMAs below
@@ -485,13 +491,23 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
         add(red);
         put(g.ws + (size_t)blockIdx.x * C::SLAB);
     }
+    if (g.bws) {                                                       // column sums: threads t, t + QD, ... own the same 4 channels
+        __syncthreads();
+        *(f32x4 *)(smem + 4 * t) = bsum;
+        __syncthreads();
+        if (t < QD) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int u = t; u < 256; u += QD) a += *(const f32x4 *)(smem + 4 * u);     // fixed order
+            *(f32x4 *)(g.bws + (size_t)blockIdx.x * COUT + 4 * t) = a;
+        }
+    }
 }
 
 // dW (OIHW, cin_real input channels) = sum of the raw slabs in workgroup order.  16 outputs per workgroup, 16 partial
 // sums each (slab s, s + 16, ...), combined by a fixed tree.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int nslab,
-                                                                   int cin_real) {
+                                                                   int cin_real, const float *__restrict__ bws, float *__restrict__ dbias) {
     constexpr int NB = COUT / 16, RG = CIN == 16 ? 9 : 3, SLAB = RG * NB * 256;
     __shared__ float part[16][17];
     const int t = threadIdx.x, e = blockIdx.x * 16 + (t & 15), s0 = t >> 4;
@@ -505,14 +521,18 @@ __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float *_
         const int el = CIN == 16 ? (ci & 3) : ci;
         const int idx = ((r * NB + (co >> 4)) * 4 + el) * 64 + ln;
         for (int s = s0; s < nslab; s += 16) v += ws[(size_t)s * SLAB + idx];
+    } else if (dbias && e < total + COUT) {                            // the blocks past dW: the bias gradient
+        for (int s = s0; s < nslab; s += 16) v += bws[(size_t)s * COUT + (e - total)];
     }
     part[t & 15][s0] = v;
     __syncthreads();
-    if (t < 16 && blockIdx.x * 16 + t < total) {
+    const int eo = blockIdx.x * 16 + t;
+    if (t < 16 && eo < total + (dbias ? COUT : 0)) {
         float a = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) a += part[t][s];
-        dw[blockIdx.x * 16 + t] = a;
+        if (eo < total) dw[eo] = a;
+        else dbias[eo - total] = a;
     }
 }
 
@@ -528,16 +548,17 @@ int narrow_wgrad_grid(int npatch, int Cin) {
 }
 
 template <int CIN, int COUT, int S, typename T>
-int narrow_wgrad_launch(NarrowW g, float *dw, int cin_real, hipStream_t st) {
+int narrow_wgrad_launch(NarrowW g, float *dw, float *dbias, int cin_real, hipStream_t st) {
     typedef NarrowWCfg<CIN, COUT, S> C;
     g.tiles_x = cdiv(g.Wo, C::TW);
     g.tiles_y = cdiv(g.Ho, C::TH);
     g.npatch = g.B * g.tiles_x * g.tiles_y;
     const int grid = narrow_wgrad_grid(g.npatch, CIN);
+    g.bws = dbias ? g.ws + (size_t)grid * C::SLAB : nullptr;
     hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S, T>), dim3(grid), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow_bwd_weight");
-    hipLaunchKernelGGL((narrow_wgrad_reduce_kernel<CIN, COUT>), dim3(cdiv(COUT * cin_real * 9, 16)), dim3(256), 0, st, g.ws, dw, grid,
-                       cin_real);
+    hipLaunchKernelGGL((narrow_wgrad_reduce_kernel<CIN, COUT>), dim3(cdiv(COUT * cin_real * 9 + (dbias ? COUT : 0), 16)), dim3(256), 0, st,
+                       g.ws, dw, grid, cin_real, g.bws, dbias);
     YH_CHECK_LAUNCH("conv_narrow_bwd_weight_reduce");
     return 0;
 }
@@ -648,13 +669,13 @@ extern "C" int64_t yh_conv_narrow_bwd_weight_ws(int B, int Hi, int Wi, int Cin, 
     const int Ho = (Hi - 1) / s + 1, Wo = (Wi - 1) / s + 1;
     const int tw = s == 1 ? 32 : (Cin == 16 ? 16 : 32);
     const int64_t npatch = (int64_t)B * cdiv(Wo, tw) * cdiv(Ho, 8);
-    const int64_t slab = (int64_t)(Cin == 16 ? 9 : 3) * (Cout / 16) * 256;
+    const int64_t slab = (int64_t)(Cin == 16 ? 9 : 3) * (Cout / 16) * 256 + Cout;      // + the column sums of dY
     return (int64_t)narrow_wgrad_grid((int)(npatch < (1 << 30) ? npatch : (1 << 30)), Cin) * slab;
 }
 
 template <typename T>
-static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float *dw, float *ws, int64_t ws_floats, int B, int Hi, int Wi,
-                               int Cin, int cin_real, int Cout, int s, void *stream) {
+static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float *dw, float *dbias, float *ws, int64_t ws_floats, int B, int Hi,
+                               int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
     YH_REQUIRE(x && dy && dw && ws && B > 0 && Hi > 0 && Wi > 0, "conv_narrow_bwd_weight: bad argument");
     YH_REQUIRE(yh_conv_narrow_bwd_weight_ok(Cin, cin_real, Cout, 3, s), "conv_narrow_bwd_weight: unsupported shape %d(%d) -> %d stride %d",
                Cin, cin_real, Cout, s);
@@ -666,16 +687,17 @@ static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float
     g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy; g.B = B; g.Hi = Hi; g.Wi = Wi;
     g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (Cin == 16 && s == 1) return narrow_wgrad_launch<16, 16, 1, T>(g, dw, cin_real, st);
-    if (Cin == 16) return narrow_wgrad_launch<16, 32, 2, T>(g, dw, cin_real, st);
-    return narrow_wgrad_launch<4, 16, 2, T>(g, dw, cin_real, st);
+    if (Cin == 16 && s == 1) return narrow_wgrad_launch<16, 16, 1, T>(g, dw, dbias, cin_real, st);
+    if (Cin == 16) return narrow_wgrad_launch<16, 32, 2, T>(g, dw, dbias, cin_real, st);
+    return narrow_wgrad_launch<4, 16, 2, T>(g, dw, dbias, cin_real, st);
 }
-extern "C" int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
-                                         int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
-    return narrow_bwd_weight_t<float>(x, ldx, dy, lddy, dw, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s, stream);
+extern "C" int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *dbias, float *ws,
+                                         int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
+    return narrow_bwd_weight_t<float>(x, ldx, dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s, stream);
 }
-extern "C" int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
-                                              int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
-    return narrow_bwd_weight_t<nbf16>((const nbf16 *)x, ldx, (const nbf16 *)dy, lddy, dw, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s,
-                                      stream);
+extern "C" int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *dbias, float *ws,
+                                              int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s,
+                                              void *stream) {
+    return narrow_bwd_weight_t<nbf16>((const nbf16 *)x, ldx, (const nbf16 *)dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout,
+                                      s, stream);
 }

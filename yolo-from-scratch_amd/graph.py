@@ -659,20 +659,24 @@ class Plan:
                 dy, lddy, kcout = r.out.gptr(), r.out.ldg, _rup8(r.cout)
                 if r.out.off != 0 or r.out.ldg != kcout:
                     raise NotImplementedError("head gradient must own its (padded) buffer")
-            if r.bias is not None:
+            fuse_bias = r.bias is not None and r.narrow_w and r.bn is not None
+            if r.bias is not None and not fuse_bias:
                 # head biases (18 / 255 channels): sum the zero-padded multiple of 4 so the vector kernel applies; the extra
                 # column sums are exact zeros and land in the 4-float padding every tensor has in the flat gradient buffer
                 cs = _rup4(r.cout) if (r.bn is None and _rup4(r.cout) <= lddy) else r.cout
                 ops.append(_op(L.OP_BF16_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, cs], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
             if r.narrow_w:
-                ops.append(_op(L.OP_BF16_CONV_NARROW_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+                ops.append(_op(L.OP_BF16_CONV_NARROW_BWD_WEIGHT,
+                               p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws, grad_of[id(r.bias)] if fuse_bias else None],
                                i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin_k, min(r.weight.shape[1], r.cin_k), r.cout, r.k, r.s],
                                l=[self.ws.numel()]))
             else:
                 ops.append(_op(L.OP_BF16_CONV_BWD_WEIGHT, p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
                                i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s], l=[self.ws.numel()]))
             self.grad_ready[id(r.weight)] = len(ops)
+            if fuse_bias:
+                self.grad_ready[id(r.bias)] = len(ops)
             if not r.need_dx:
                 continue
             if r.pair is not None:
@@ -765,15 +769,18 @@ class Plan:
                 self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
             else:
                 dy, lddy = r.out.gptr(), r.out.ld
-            if r.bias is not None:
+            fuse_bias = r.bias is not None and r.narrow_w          # the narrow weight-gradient kernel also sums dY's columns
+            if r.bias is not None and not fuse_bias:
                 ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
             ops.append(_op(L.OP_CONV_NARROW_BWD_WEIGHT if r.narrow_w else L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else
                            (L.OP_CONV_PW_BWD_WEIGHT if r.pw_w else L.OP_CONV_BWD_WEIGHT),
-                           p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws],
+                           p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws, grad_of[id(r.bias)] if fuse_bias else None],
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
                            l=[self.ws.numel()]))
             self.grad_ready[id(r.weight)] = len(ops)
+            if fuse_bias:
+                self.grad_ready[id(r.bias)] = len(ops)
             if r.need_dx and r.pair is not None:
                 if id(r.pair) in pair_pending:      # second of the pair (in backward order): both dY are final now
                     first, second = (r, r.pair) if r.pair_first else (r.pair, r)
