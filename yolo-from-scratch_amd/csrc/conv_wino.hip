@@ -688,6 +688,164 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
+// The same computation with the operands STAGED THROUGH LDS.  In-kernel stamps of the register-direct kernel above: the loop
+// runs at 2.7x its MFMA issue time -- per 8 MFMAs a wave issues 8 + 4 load instructions of 4 (8) bytes per lane, and the four
+// waves of a workgroup load overlapping pixels: the texture path, not the matrix pipe, sets the pace.  Here a workgroup walks
+// STRIPS of G consecutive tiles of one tile row: the 4 x (2G + 2) input pixels and the 2 x 2G output-gradient pixels of the
+// strip are fetched once with 16-byte loads (next strip in flight in registers under the current one's MFMAs), parked as
+// Xs[row][pixel][32 channels] / Ds[row][pixel][32 NT channels], and every operand read is a conflict-free ds_read_b32 /
+// ds_read_b64 of consecutive channels.  Same transforms, accumulators, slab layout and fixed-order reduction.
+struct WinoWL {
+    const float *x, *dy;
+    float *ws;
+    int ldx, lddy;
+    int B, H, W, Cin, Cout;
+    int TW, TH, G, spr, nstrips, sps;   // G tiles per strip (even), strips per tile row, total strips, strips per split
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_lds_kernel(const WinoWL g) {
+    constexpr int GMAX = 16, PWMAX = 2 * GMAX + 2;
+    constexpr int XPIECES_MAX = 4 * PWMAX * 8, DPIECES_MAX = 2 * 2 * GMAX * 8 * NT;
+    constexpr int NXP = (XPIECES_MAX + 255) / 256, NDP = (DPIECES_MAX + 255) / 256;
+    constexpr int BNW = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // Xs | Ds during the loop, T[4][32][BNW] in the epilogue
+    float *Xs = smem, *Ds = smem + 4 * PWMAX * 32;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * BNW;
+    const int G = g.G, PW = 2 * G + 2, DW = 2 * G;
+
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+    const float ca = wave == 3 ? 0.f : 1.f;                    // row xi of A: (1,0) (1,1) (1,-1) (0,-1)
+    const float cb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+
+    // staging plan (fixed for the kernel): piece k of this thread -> (row, pixel, channel quad); -1 = none
+    int xrow[NXP], xpix[NXP], xq[NXP], drow[NDP], dpix[NDP], dq[NDP];
+#pragma unroll
+    for (int k = 0; k < NXP; ++k) {
+        const int i = t + 256 * k, q = i & 7, pp = i >> 3;
+        xq[k] = q; xpix[k] = pp % PW; xrow[k] = pp / PW;
+        if (xrow[k] >= 4) xrow[k] = -1;
+    }
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) {
+        const int i = t + 256 * k, q = i % (8 * NT), pp = i / (8 * NT);
+        dq[k] = q; dpix[k] = pp % DW; drow[k] = pp / DW;
+        if (drow[k] >= 2) drow[k] = -1;
+    }
+    // element offsets of the pieces from the strip's origin pixel (fixed for the kernel: one 64-bit base per strip, then an add
+    // and two compares per piece -- the full address arithmetic per piece cost ~40 % of a strip's MFMA time)
+    int xoff[NXP], doff[NDP];
+#pragma unroll
+    for (int k = 0; k < NXP; ++k) xoff[k] = (xrow[k] * g.W + xpix[k]) * g.ldx + 4 * xq[k];
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) doff[k] = (drow[k] * g.W + dpix[k]) * g.lddy + 4 * dq[k];
+    f32x4 rx[NXP], rd[NDP];
+    auto fetch = [&](int sid) {
+        const int sx = sid % g.spr, rest = sid / g.spr;
+        const int ty = rest % g.TH, b = rest / g.TH;
+        const int ix0 = 2 * sx * G - 1, iy0 = 2 * ty - 1;
+        const float *xbase = g.x + ((ptrdiff_t)(b * g.H + iy0) * g.W + ix0) * g.ldx + ci0;
+        const float *dbase = g.dy + ((ptrdiff_t)(b * g.H + 2 * ty) * g.W + 2 * sx * G) * g.lddy + co0;
+        const int wleft = g.W - 2 * sx * G;                // dY pixels of this strip that exist
+#pragma unroll
+        for (int k = 0; k < NXP; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (xrow[k] >= 0 && (unsigned)(iy0 + xrow[k]) < (unsigned)g.H && (unsigned)(ix0 + xpix[k]) < (unsigned)g.W)
+                v = *(const f32x4 *)(xbase + xoff[k]);
+            rx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (drow[k] >= 0 && dpix[k] < wleft) v = *(const f32x4 *)(dbase + doff[k]);
+            rd[k] = v;
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int k = 0; k < NXP; ++k)
+            if (xrow[k] >= 0) *(f32x4 *)(Xs + (xrow[k] * PWMAX + xpix[k]) * 32 + 4 * xq[k]) = rx[k];
+#pragma unroll
+        for (int k = 0; k < NDP; ++k)
+            if (drow[k] >= 0) *(f32x4 *)(Ds + (drow[k] * 2 * GMAX + dpix[k]) * BNW + 4 * dq[k]) = rd[k];
+    };
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
+
+    const int s_begin = blockIdx.x * g.sps;
+    int s_end = s_begin + g.sps;
+    if (s_end > g.nstrips) s_end = g.nstrips;
+    // operand addresses of this lane inside a strip: tile 2 s + lh, channel lr (x) / NT lr (dy)
+    const float *xa = Xs + (ra * PWMAX + 2 * lh) * 32 + lr, *xb = Xs + (rb * PWMAX + 2 * lh) * 32 + lr;
+    const float *d0 = Ds + (2 * lh) * BNW + NT * lr, *d1 = d0 + 2 * GMAX * BNW;
+    if (s_begin < s_end) fetch(s_begin);
+    for (int sid = s_begin; sid < s_end; ++sid) {
+        __syncthreads();                                   // the previous strip's operands are consumed
+        park();
+        __syncthreads();
+        if (sid + 1 < s_end) fetch(sid + 1);               // in flight under the MFMAs below
+        for (int ks = 0; ks < G / 2; ++ks) {               // one k-step = the tile pair (2 ks, 2 ks + 1)
+            const int po = 4 * ks * 32;                    // 4 pixels per tile pair
+            float tt[4], V[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) tt[cc] = xa[po + cc * 32] + sg * xb[po + cc * 32];
+            V[0] = tt[0] - tt[2];
+            V[1] = tt[1] + tt[2];
+            V[2] = tt[2] - tt[1];
+            V[3] = tt[1] - tt[3];
+            const int dofs = 4 * ks * BNW;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float r0 = ca * d0[dofs + j] + cb * d1[dofs + j];
+                const float r1 = ca * d0[dofs + BNW + j] + cb * d1[dofs + BNW + j];
+                const float dM[4] = {r0, r0 + r1, r0 - r1, -r1};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v], dM[v], acc[v][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- dg = G^T dU G (as in wino_wgrad_kernel): nu-contraction lane-local, xi-contraction through LDS, one filter column per pass
+    __syncthreads();
+    float *T = smem;                           // [xi 4][row 32][col BNW]
+    float *slab = g.ws + (size_t)blockIdx.x * 9 * g.Cin * g.Cout;
+    const size_t tapstride = (size_t)g.Cin * g.Cout;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float a0 = acc[0][j][r], a1 = acc[1][j][r], a2 = acc[2][j][r], a3 = acc[3][j][r];
+                float v = b == 0 ? a0 + 0.5f * (a1 + a2) : (b == 1 ? 0.5f * (a1 - a2) : 0.5f * (a1 + a2) + a3);
+                T[(wave * 32 + row) * BNW + NT * lr + j] = v;
+            }
+        __syncthreads();
+        for (int e = t; e < 32 * BNW; e += 256) {
+            int col = e % BNW, row = e / BNW;
+            float T0 = T[(0 * 32 + row) * BNW + col], T1 = T[(1 * 32 + row) * BNW + col];
+            float T2 = T[(2 * 32 + row) * BNW + col], T3 = T[(3 * 32 + row) * BNW + col];
+            float h = 0.5f * (T1 + T2);
+            size_t o = (size_t)(ci0 + row) * g.Cout + co0 + col;
+            slab[(0 * 3 + b) * tapstride + o] = T0 + h;
+            slab[(1 * 3 + b) * tapstride + o] = 0.5f * (T1 - T2);
+            slab[(2 * 3 + b) * tapstride + o] = h + T3;
+        }
+    }
+}
+
 // ws [nsplit][9][Cin][Cout] -> dw OIHW: 16 split-lanes each add every 16th slab, lanes combined in order (the
 // summation order is fixed).
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int nsplit,
@@ -778,6 +936,34 @@ int launch_wino(Wino &g, hipStream_t st) {
 }  // namespace
 
 namespace {
+// strips of the LDS-staged kernel: G tiles (even, <= 16) per strip with the least padding of the tile row
+int wgrad_lds_plan(WinoWL &g, int &nsplit, int &NT, int B, int H, int W, int Cin, int Cout) {
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+    g.TW = W / 2; g.TH = H / 2;
+    int best = 16, bestpad = 1 << 30;
+    for (int G = 16; G >= 8; G -= 2) {
+        const int pad = cdiv(g.TW, G) * G;
+        if (pad < bestpad) { bestpad = pad; best = G; }
+    }
+    if (g.TW < 8) best = (g.TW + 1) & ~1;
+    g.G = best;
+    g.spr = cdiv(g.TW, g.G);
+    g.nstrips = B * g.TH * g.spr;
+    NT = Cout % 64 == 0 ? 2 : 1;
+    const int pairs = (Cin / 32) * (Cout / (32 * NT));
+    static const int target = getenv("YH_WINO_WGRAD_BLOCKS") ? atoi(getenv("YH_WINO_WGRAD_BLOCKS")) : 512;
+    nsplit = target / pairs;
+    if (nsplit < 1) nsplit = 1;
+    g.sps = cdiv(g.nstrips, nsplit);
+    if (g.sps < 4) g.sps = 4;
+    nsplit = cdiv(g.nstrips, g.sps);
+    return 0;
+}
+inline bool wino_wgrad_use_lds() {
+    static const bool on = !(getenv("YH_WINO_WGRAD_LDS") && atoi(getenv("YH_WINO_WGRAD_LDS")) == 0);
+    return on;
+}
+
 int wgrad_plan(WinoW &g, int &nsplit, int &NT, int B, int H, int W, int Cin, int Cout) {
     YH_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 32 == 0, "conv_wino_bwd_weight: even H, W and channels % 32 == 0");
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
@@ -801,7 +987,10 @@ extern "C" int64_t yh_conv_wino_bwd_weight_ws(int B, int H, int W, int Cin, int 
     WinoW g{};
     int nsplit, NT;
     if (wgrad_plan(g, nsplit, NT, B, H, W, Cin, Cout)) return -1;
-    return (int64_t)nsplit * 9 * Cin * Cout;
+    WinoWL gl{};
+    int nsplit2 = 0, NT2;
+    wgrad_lds_plan(gl, nsplit2, NT2, B, H, W, Cin, Cout);
+    return (int64_t)(nsplit > nsplit2 ? nsplit : nsplit2) * 9 * Cin * Cout;       // either kernel may run (YH_WINO_WGRAD_LDS)
 }
 
 extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
@@ -821,6 +1010,23 @@ extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy,
     g.x_bytes = (unsigned)(((npix - 1) * ldx + Cin) * 4);
     g.dy_bytes = (unsigned)(((npix - 1) * lddy + Cout) * 4);
     hipStream_t st = (hipStream_t)stream;
+    if (wino_wgrad_use_lds() && ldx % 4 == 0 && lddy % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0) {
+        WinoWL gl{};
+        int ns2, NT2;
+        wgrad_lds_plan(gl, ns2, NT2, B, H, W, Cin, Cout);
+        YH_REQUIRE(ws_floats >= (int64_t)ns2 * 9 * Cin * Cout, "conv_wino_bwd_weight: workspace too small");
+        gl.x = x; gl.dy = dy; gl.ws = ws; gl.ldx = ldx; gl.lddy = lddy;
+        dim3 grid2(ns2, Cin / 32, Cout / (32 * NT2));
+        const size_t stage = (size_t)(4 * 34 * 32 + 2 * 32 * 32 * NT2) * sizeof(float), epi = (size_t)4 * 32 * 32 * NT2 * sizeof(float);
+        const size_t smem2 = stage > epi ? stage : epi;
+        if (NT2 == 2) hipLaunchKernelGGL((wino_wgrad_lds_kernel<2>), grid2, dim3(256), smem2, st, gl);
+        else hipLaunchKernelGGL((wino_wgrad_lds_kernel<1>), grid2, dim3(256), smem2, st, gl);
+        YH_CHECK_LAUNCH("wino_wgrad_lds");
+        const int n2 = 9 * Cin * Cout;
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n2, 16)), dim3(256), 0, st, ws, dw, ns2, Cin, Cout);
+        YH_CHECK_LAUNCH("wino_wgrad_reduce");
+        return 0;
+    }
     dim3 grid(nsplit, Cin / 32, Cout / (32 * NT));
     // two waves per SIMD hide each other's address arithmetic for the 64-column variant (0.222 -> 0.187 ms on 64->64 @80^2);
     // the 32-column variant spills at that register budget and stays at one
