@@ -23,7 +23,7 @@ from provenance import stamp
 FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "stem_conv_kernel", "bf16_gemm_kernel",
             "narrow_conv_kernel")
 DGRAD_ONLY = ("narrow_dgrad_s2_kernel",)
-WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "wgrad_reduce")
+WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "wino_wgrad_lds_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "wgrad_reduce")
 
 
 def short(name):
