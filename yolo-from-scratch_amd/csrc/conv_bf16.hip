@@ -16,6 +16,7 @@
 // MFMA operand maps (cdna guide section 3): v_mfma_f32_32x32x16_bf16, lane l (r = l & 31, h = l >> 5) holds
 // A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7; D register q of lane l = D[(q & 3) + 8 (q >> 2) + 4h][col r].
 #include "common.h"
+#include <type_traits>
 #ifdef YH_BF_STAMPS
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,6 +67,14 @@ __device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
 
 __device__ __forceinline__ int mfma_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
 
+// output pixel of GEMM row m (dense: the rows are the output pixels in order; otherwise a strided / offset sub-grid)
+__device__ __forceinline__ size_t out_pixel(const BfGemm &g, int m) {
+    if (g.dense) return (size_t)m;
+    int qq = fast_div(m, g.xo_magic, g.xo_shift), x = m - qq * g.Xo;
+    int b = fast_div(qq, g.yo_magic, g.yo_shift), y = qq - b * g.Yo;
+    return ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
+}
+
 // C64: every class has Cin % 64 == 0, i.e. a 64-wide K chunk never straddles two taps.  The chunk's tap, its pixel
 // displacement and its weight rows are then the same for the whole workgroup (scalar work), and what is left per load is a
 // bounds test and an add.  The counters say why this matters: at bf16 MFMA rates a chunk's 16 MFMAs take ~500 cycles per wave
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     constexpr int BPASS = (8 * BN + 255) / 256;
     constexpr int C_STRIDE = BN * 2 + 16;    // bytes per row of the epilogue staging tile
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile shape");
+    static_assert((8 * BN) % 256 == 0, "the B tile must be a whole number of 256-thread passes");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *As = smem;                              // [2][BM][A_STRIDE]
@@ -136,7 +146,13 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
         bnn[p] = n0 + (e - bo[p] * BN);
         if (bo[p] >= 8 || bnn[p] >= g.ldw) bo[p] = 1 << 20;         // never valid
     }
-    auto load_tiles = [&](int c, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS]) {
+    // Every load is issued unconditionally: a piece that lies outside the image / past K reads a valid dummy address and
+    // is zeroed when it is written to LDS (validity bits travel with the register set).  A load inside a branch cannot be
+    // counted by the compiler's s_waitcnt bookkeeping, which then waits with vmcnt(0) before the next set is requested --
+    // the distance-2 prefetch below silently became distance 1.
+    unsigned mkA = 0, mkB = 0;              // bits 0..AROWS-1: A pieces, bits 8..8+BPASS-1: B pieces
+    auto load_tiles = [&](int c, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS], unsigned &mk) {
+        unsigned m = 0;
         if (C64) {
             const int k0 = c * BK;                                   // workgroup-uniform from here on
             const int tap = (int)__umulhi((unsigned)k0, g.cin_magic), ci0 = k0 - tap * g.Cin;
@@ -146,52 +162,58 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
 #pragma unroll
             for (int i = 0; i < AROWS; ++i) {
                 const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
-                ra[i] = ok ? *(const u32x4 *)(inb + (roff[i] + toff)) : u32x4{0u, 0u, 0u, 0u};
+                m |= (unsigned)ok << i;
+                ra[i] = *(const u32x4 *)(ok ? inb + (roff[i] + toff) : g.in);
             }
             const bf16 *wrow = g.w + ((size_t)(tapt[18 + tap] * cin8 + (ci0 >> 3)) * g.ldw << 3);
             const int orem = (g.Ktot - k0) >> 3;                     // octet rows left in K (>= 8 except in a ragged last chunk)
 #pragma unroll
-            for (int p = 0; p < BPASS; ++p)
-                rb[p] = bo[p] < orem ? *(const u32x4 *)(wrow + ((size_t)(bo[p] * g.ldw + bnn[p]) << 3)) : u32x4{0u, 0u, 0u, 0u};
+            for (int p = 0; p < BPASS; ++p) {
+                const bool ok = bo[p] < orem;
+                m |= (unsigned)ok << (8 + p);
+                rb[p] = *(const u32x4 *)(ok ? wrow + ((size_t)(bo[p] * g.ldw + bnn[p]) << 3) : g.w);
+            }
+            mk = m;
             return;
         }
         const int k = c * BK + 8 * kq;
-        if (k < g.Ktot) {
-            int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
+        {
+            const bool kok = k < g.Ktot;
+            const int kk = kok ? k : 0;
+            int tap = (int)__umulhi((unsigned)kk, g.cin_magic), ci = kk - tap * g.Cin;
             int dy = tapt[tap], dx = tapt[9 + tap];
             int toff = (dy * g.Wi + dx) * g.ldi + ci;
-            const bf16 *inb = (g.in2 && k >= g.ksplit) ? g.in2 - g.ksplit : g.in;
+            const bf16 *inb = (g.in2 && kk >= g.ksplit) ? g.in2 - g.ksplit : g.in;
 #pragma unroll
             for (int i = 0; i < AROWS; ++i) {
-                bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
-                ra[i] = ok ? *(const u32x4 *)(inb + (roff[i] + toff)) : u32x4{0u, 0u, 0u, 0u};
+                const bool ok = kok && (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
+                m |= (unsigned)ok << i;
+                ra[i] = *(const u32x4 *)(ok ? inb + (roff[i] + toff) : g.in);
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < AROWS; ++i) ra[i] = u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             int e = t + 256 * p;
             int o = e / BN, n = n0 + (e - o * BN);
             int kr = c * BK + 8 * o;
-            if (o < 8 && kr < g.Ktot && n < g.ldw) {
-                int tap = (int)__umulhi((unsigned)kr, g.cin_magic), ci = kr - tap * g.Cin;
-                rb[p] = *(const u32x4 *)(g.w + ((size_t)((tapt[18 + tap] * cin8 + (ci >> 3)) * g.ldw + n) << 3));
-            } else {
-                rb[p] = u32x4{0u, 0u, 0u, 0u};
-            }
+            const bool ok = o < 8 && kr < g.Ktot && n < g.ldw;
+            const int krr = ok ? kr : 0;
+            int tap = (int)__umulhi((unsigned)krr, g.cin_magic), ci = krr - tap * g.Cin;
+            m |= (unsigned)ok << (8 + p);
+            rb[p] = *(const u32x4 *)(ok ? g.w + ((size_t)((tapt[18 + tap] * cin8 + (ci >> 3)) * g.ldw + n) << 3) : g.w);
         }
+        mk = m;
     };
-    auto store_tiles = [&](int buf, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS]) {
+    auto store_tiles = [&](int buf, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS], unsigned mk) {
         unsigned char *a = As + buf * BM * A_STRIDE;
         unsigned char *b = Bs + buf * 8 * BN * 16;
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < AROWS; ++i) *(u32x4 *)(a + ((t >> 3) + 32 * i) * A_STRIDE + 16 * kq) = ra[i];
+        for (int i = 0; i < AROWS; ++i) *(u32x4 *)(a + ((t >> 3) + 32 * i) * A_STRIDE + 16 * kq) = (mk >> i) & 1u ? ra[i] : z;
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
-            int e = t + 256 * p;
-            if (e < 8 * BN) *(u32x4 *)(b + e * 16) = rb[p];
+            const int e = t + 256 * p;          // < 8 BN for every piece: the tile is a whole number of passes
+            *(u32x4 *)(b + e * 16) = (mk >> (8 + p)) & 1u ? rb[p] : z;
         }
     };
 
@@ -210,35 +232,59 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     auto compute = [&](int buf, int kvalid) {
         const unsigned char *a = As + buf * BM * A_STRIDE + (wm * TM * 32 + lr) * A_STRIDE + 16 * lh;
         const unsigned char *b = Bs + buf * 8 * BN * 16 + (lh * BN + wn * TN * 32 + lr) * 16;
+        // fragments of k-step ks+1 are requested before the MFMAs of step ks (a step past kvalid multiplies staged zeros
+        // only when it is skipped: reading it is harmless, the tile is fully written)
+        bf16x8 av[2][TM], bv[2][TN];
+        auto frag = [&](int ks, bf16x8 (&x)[TM], bf16x8 (&y)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) x[i] = *(const bf16x8 *)(a + i * 32 * A_STRIDE + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) y[j] = *(const bf16x8 *)(b + (2 * ks * BN + j * 32) * 16);
+        };
+        frag(0, av[0], bv[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks * 16 >= kvalid) break;
-            bf16x8 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *(const bf16x8 *)(a + i * 32 * A_STRIDE + ks * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *(const bf16x8 *)(b + (2 * ks * BN + j * 32) * 16);
+            if (ks < 3) frag(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
         }
     };
     // software pipeline, prefetch distance 2: at step c the loads of chunk c+2 are issued, chunk c is multiplied from LDS,
-    // then chunk c+1 (loaded one step earlier) is written to the other LDS buffer
-    load_tiles(0, raA, rbA);
-    store_tiles(0, raA, rbA);
-    if (nchunks > 1) load_tiles(1, raB, rbB);
+    // then chunk c+1 (loaded one step earlier) is written to the other LDS buffer.  The steady state is a branch-free
+    // loop (full chunks, both requests unconditional) so that the waits count exactly one register set; the last one to
+    // three chunks run in the guarded tail.
+    load_tiles(0, raA, rbA, mkA);
+    store_tiles(0, raA, rbA, mkA);
+    if (nchunks > 1) load_tiles(1, raB, rbB, mkB);
     __syncthreads();
-    for (int c = 0; c < nchunks; c += 2) {
-        if (c + 2 < nchunks) load_tiles(c + 2, raA, rbA);
+    int c = 0;
+    for (; c + 3 < nchunks; c += 2) {
+        load_tiles(c + 2, raA, rbA, mkA);
+        __builtin_amdgcn_sched_barrier(0);      // requests first: the scheduler otherwise sinks them below the MFMAs
+        compute(0, BK);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(1, raB, rbB, mkB);
+        __syncthreads();
+        load_tiles(c + 3, raB, rbB, mkB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, BK);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(0, raA, rbA, mkA);
+        __syncthreads();
+    }
+    for (; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) load_tiles(c + 2, raA, rbA, mkA);
         compute(0, g.Ktot - c * BK);
-        if (c + 1 < nchunks) store_tiles(1, raB, rbB);
+        if (c + 1 < nchunks) store_tiles(1, raB, rbB, mkB);
         __syncthreads();
         if (c + 1 >= nchunks) break;
-        if (c + 3 < nchunks) load_tiles(c + 3, raB, rbB);
+        if (c + 3 < nchunks) load_tiles(c + 3, raB, rbB, mkB);
         compute(1, g.Ktot - (c + 1) * BK);
-        if (c + 2 < nchunks) store_tiles(0, raA, rbA);
+        if (c + 2 < nchunks) store_tiles(0, raA, rbA, mkA);
         __syncthreads();
     }
 
@@ -257,46 +303,66 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
     unsigned char *Cs = smem;              // [BM][C_STRIDE] (the main loop ended with a barrier)
+    // Three straight-line variants chosen by workgroup-uniform tests.  One loop with the tests inside was compiled to a
+    // chain of scalar branches and exec-mask updates per ELEMENT (64 per thread): the in-kernel stamps put 3.4k / 7k / 9-15k
+    // cycles on this phase for BN = 32 / 64 / 128 -- more than the whole main loop of a pointwise layer.
+    const bool whole = m0 + BM <= g.M && n0 + BN <= g.N;
+    if (staged && whole) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int rl = wm * TM * 32 + i * 32 + mfma_row(q, lh);
-            const int m = m0 + rl;
-            if (staged) {
+            for (int q = 0; q < 16; ++q) {
+                unsigned char *row = Cs + (wm * TM * 32 + i * 32 + mfma_row(q, lh)) * C_STRIDE + (wn * TN * 32 + lr) * 2;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16 hv = (bf16)(acc[i][j][q] + bias_v[j]);
+                    *(bf16 *)(row + j * 64) = hv;
+                    const float vq = (float)hv;
+                    csum[j] += vq;
+                    csq[j] += vq * vq;
+                }
+            }
+    } else if (staged) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rl = wm * TM * 32 + i * 32 + mfma_row(q, lh);
+                const bool rok = m0 + rl < g.M;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int cl = wn * TN * 32 + j * 32 + lr;
-                    bf16 hv = (bf16)(acc[i][j][q] + bias_v[j]);
+                    const bf16 hv = (bf16)(acc[i][j][q] + bias_v[j]);
                     *(bf16 *)(Cs + rl * C_STRIDE + cl * 2) = hv;
-                    if (m < g.M && n0 + cl < g.N) {
-                        float vq = (float)hv;
-                        csum[j] += vq;
-                        csq[j] += vq * vq;
-                    }
+                    const float vq = (rok && n0 + cl < g.N) ? (float)hv : 0.f;
+                    csum[j] += vq;
+                    csq[j] += vq * vq;
                 }
-            } else if (m < g.M) {
-                size_t opix;
-                if (g.dense) {
-                    opix = (size_t)m;
-                } else {
-                    int qq = fast_div(m, g.xo_magic, g.xo_shift), x = m - qq * g.Xo;
-                    int b = fast_div(qq, g.yo_magic, g.yo_shift), y = qq - b * g.Yo;
-                    opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
-                }
+            }
+    } else {
+        // (always_inline: a closure that is called would take the address of the kernel-argument struct, which then lives in scratch)
+        auto direct = [&](auto f32_c, auto acc_c) __attribute__((always_inline)) {
+            constexpr bool F32 = decltype(f32_c)::value, ACC = decltype(acc_c)::value;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * TN * 32 + j * 32 + lr;
-                    if (n < g.N) {
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + wm * TM * 32 + i * 32 + mfma_row(q, lh);
+                    if (m >= g.M) continue;
+                    const size_t obase = out_pixel(g, m) * g.ldo;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wn * TN * 32 + j * 32 + lr;
+                        if (n >= g.N) continue;
                         float v = acc[i][j][q] + bias_v[j];
-                        if (g.out_f32) {
-                            float *o = (float *)g.out + opix * g.ldo + n;
-                            if (g.accumulate) v += *o;
+                        if (F32) {
+                            float *o = (float *)g.out + obase + n;
+                            if (ACC) v += *o;
                             *o = v;
                         } else {
-                            bf16 *o = (bf16 *)g.out + opix * g.ldo + n;
-                            if (g.accumulate) v += (float)*o;
-                            bf16 hv = (bf16)v;
+                            bf16 *o = (bf16 *)g.out + obase + n;
+                            if (ACC) v += (float)*o;
+                            const bf16 hv = (bf16)v;
                             *o = hv;
                             v = (float)hv;
                         }
@@ -304,26 +370,27 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
                         csq[j] += v * v;
                     }
                 }
-            }
+        };
+        if (g.out_f32) {
+            if (g.accumulate) direct(std::true_type{}, std::true_type{});
+            else direct(std::true_type{}, std::false_type{});
+        } else {
+            if (g.accumulate) direct(std::false_type{}, std::true_type{});
+            else direct(std::false_type{}, std::false_type{});
         }
     }
+#ifdef YH_BF_STAMPS
+    const unsigned long long se1 = __builtin_amdgcn_s_memtime();
+#endif
     if (staged) {
         __syncthreads();
         constexpr int PCS = BN / 8;            // 16-byte pieces per row
         for (int p = t; p < BM * PCS; p += 256) {
             const int rl = p / PCS, oc = p - rl * PCS;
             const int m = m0 + rl, n = n0 + 8 * oc;
-            if (m >= g.M || n >= g.N) continue;
-            size_t opix;
-            if (g.dense) {
-                opix = (size_t)m;
-            } else {
-                int qq = fast_div(m, g.xo_magic, g.xo_shift), x = m - qq * g.Xo;
-                int b = fast_div(qq, g.yo_magic, g.yo_shift), y = qq - b * g.Yo;
-                opix = ((size_t)b * g.Ho_f + (y * g.osy + g.ooy)) * g.Wo_f + (x * g.osx + g.oox);
-            }
+            if (!whole && (m >= g.M || n >= g.N)) continue;
             bf16x8 v = *(const bf16x8 *)(Cs + rl * C_STRIDE + oc * 16);
-            bf16 *o = (bf16 *)g.out + opix * g.ldo + n;
+            bf16 *o = (bf16 *)g.out + out_pixel(g, m) * g.ldo + n;
             if (g.accumulate) {
                 bf16x8 old = *(const bf16x8 *)o;
                 f32x8 s = __builtin_convertvector(v, f32x8) + __builtin_convertvector(old, f32x8);
@@ -332,6 +399,9 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
             *(bf16x8 *)o = v;
         }
     }
+#ifdef YH_BF_STAMPS
+    const unsigned long long se2 = __builtin_amdgcn_s_memtime();
+#endif
     if (g.stats) {
         __syncthreads();
         float *red = (float *)(smem + BM * C_STRIDE);     // [WM][BN][2], behind the staging tile
@@ -358,8 +428,9 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     }
 #ifdef YH_BF_STAMPS
     if (g.dbg && t == 0 && (NCLS == 1 || blockIdx.y == 0)) {
-        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
+        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 8;
         d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+        d[6] = se1; d[7] = se2;
     }
 #endif
 }
@@ -402,7 +473,7 @@ int launch_cfg2(BfGemmSet &gs, hipStream_t st) {
 #ifdef YH_BF_STAMPS
     static unsigned long long *dbgbuf = nullptr;
     if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
-    const bool dbg_on = getenv("YH_BF_DBG") && (size_t)maxblk * 48 <= ((size_t)1 << 24);
+    const bool dbg_on = getenv("YH_BF_DBG") && (size_t)maxblk * 64 <= ((size_t)1 << 24);
     for (int c = 0; c < NCLS; ++c) gs.c[c].dbg = dbg_on ? dbgbuf : nullptr;
 #endif
     hipLaunchKernelGGL(kern, dim3(maxblk, NCLS), dim3(256), smem, st, gs);
@@ -410,19 +481,20 @@ int launch_cfg2(BfGemmSet &gs, hipStream_t st) {
 #ifdef YH_BF_STAMPS
     if (dbg_on) {
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)maxblk * 6);
+        std::vector<unsigned long long> h((size_t)maxblk * 8);
         (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
-        double a = 0, b = 0, c2 = 0, rt = 0; unsigned long long lo = ~0ull, hi = 0;
+        double a = 0, b = 0, c2 = 0, rt = 0, e1 = 0, e2 = 0; unsigned long long lo = ~0ull, hi = 0;
         for (int i = 0; i < maxblk; ++i) {
-            a += (double)(h[6 * i + 1] - h[6 * i]); b += (double)(h[6 * i + 2] - h[6 * i + 1]); c2 += (double)(h[6 * i + 3] - h[6 * i + 2]);
-            rt += (double)(h[6 * i + 5] - h[6 * i + 4]);
-            if (h[6 * i + 4] < lo) lo = h[6 * i + 4];
-            if (h[6 * i + 5] > hi) hi = h[6 * i + 5];
+            a += (double)(h[8 * i + 1] - h[8 * i]); b += (double)(h[8 * i + 2] - h[8 * i + 1]); c2 += (double)(h[8 * i + 3] - h[8 * i + 2]);
+            e1 += (double)(h[8 * i + 6] - h[8 * i + 2]); e2 += (double)(h[8 * i + 7] - h[8 * i + 6]);
+            rt += (double)(h[8 * i + 5] - h[8 * i + 4]);
+            if (h[8 * i + 4] < lo) lo = h[8 * i + 4];
+            if (h[8 * i + 5] > hi) hi = h[8 * i + 5];
         }
         const BfGemm &g0 = gs.c[0];
         const double mf = (double)((g0.Ktot + 63) / 64) * (BM / WM / 32) * (BN / WN / 32) * 4 * 32.4;
-        fprintf(stderr, "[bf16 stamps] BM %d BN %d NCLS %d M %d N %d K %d wgs %d: setup %.0f, loop %.0f (MFMA issue floor %.0f), epilogue %.0f cycles = %.2f us per workgroup (clock %.2f GHz); span %.1f us\n",
-                BM, BN, NCLS, g0.M, g0.N, g0.Ktot, maxblk, a / maxblk, b / maxblk, mf, c2 / maxblk, rt / maxblk / 100.0, (a + b + c2) / rt * 0.1, (double)(hi - lo) / 100.0);
+        fprintf(stderr, "[bf16 stamps] BM %d BN %d NCLS %d M %d N %d K %d wgs %d: setup %.0f, loop %.0f (MFMA issue floor %.0f), epilogue %.0f (stage %.0f, store %.0f) cycles = %.2f us per workgroup (clock %.2f GHz); span %.1f us\n",
+                BM, BN, NCLS, g0.M, g0.N, g0.Ktot, maxblk, a / maxblk, b / maxblk, mf, c2 / maxblk, e1 / maxblk, e2 / maxblk, rt / maxblk / 100.0, (a + b + c2) / rt * 0.1, (double)(hi - lo) / 100.0);
     }
 #endif
     return 0;
