@@ -156,20 +156,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
         };
         const float x = p[4], z = t[4];
         lobj = (double)bce_logits(x, z);
-        if (hasd) {
-            // Every cell writes its objectness gradient; all its other gradients are zero unless it holds a target.  A lone
-            // 2-byte store makes the memory side read-modify-write the whole line (measured: 4x the traffic and 9x the time of
-            // the fp32 path), so a bf16 cell without a target writes the aligned 32-bit word around element 4 -- the partner
-            // half is element 3 or 5 of the SAME cell, zero here and rewritten below when the cell does hold a target.
-            const float go = (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]);
-            const bool odd = ((dbase + 4) & 1) != 0;
-            if (a.dbf16 && (odd || a.nc > 0) && (((uintptr_t)a.dpred[s]) & 3) == 0) {
-                const unsigned h = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)go);
-                ((unsigned *)a.dpred[s])[(dbase + 4) >> 1] = odd ? h << 16 : h;
-            } else {
-                dstore(4, go);
-            }
-        }
+        if (hasd) dstore(4, (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]));
         if (z > 0.5f) {
             int an = (int)(cell % 3);
             int64_t q = cell / 3;
