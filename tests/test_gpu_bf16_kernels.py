@@ -153,6 +153,53 @@ def test_bf16_conv_fwd_dgrad_wgrad(case):
     assert torch.equal(dw, dw2)                                               # deterministic
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", [(2, 13, 11, 64, 24, 1, 1), (1, 17, 9, 32, 40, 3, 1), (2, 10, 14, 16, 16, 3, 2)])
+def test_bf16_conv_direct_store_variants(B, H, W, Cin, Cout, k, s):
+    """Outputs whose row pitch is not a multiple of 8 elements cannot take the staged 16-byte stores: forward and
+    backward-data (plain and accumulating) then run the element-wise epilogue variants of bf16_gemm_kernel, ragged
+    tiles included.  Same oracle and tolerance as above; channels next to the view must stay untouched."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(B * 1000 + H * 100 + Cout)
+    st = torch.cuda.current_stream().cuda_stream
+    x = bf(torch.randn(B, Cin, H, W))
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    wq = bf(w)
+    p = k // 2
+    ref = F.conv2d(x.double(), wq.double(), None, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xg = nhwc_bf16(x)
+    wf, ldf, wb, ldb = pack(L, w.cuda(), Cin)
+    nblk = lib.yh_bf16_conv_blocks(B * Ho * Wo)
+    part = torch.zeros(nblk * 2 * Cout, device="cuda")
+    ld = Cout + 4                                   # 8-byte aligned rows only
+    ybuf = torch.full((B, Ho, Wo, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    yv = ybuf.view(-1)[4:]
+    L.check(lib.yh_bf16_conv_fwd(xg.data_ptr(), Cin, wf.data_ptr(), ldf, None, yv.data_ptr(), ld, 0, part.data_ptr(),
+                                 B, H, W, Cin, Cout, k, s, st), "fwd")
+    y = ybuf[..., 4:].float().permute(0, 3, 1, 2)
+    assert rel_err(y, ref) < BF16_OUT_TOL
+    assert bool((ybuf[..., :4] == 7.0).all())
+    ps = part.view(nblk, 2, Cout).sum(0).cpu().double()
+    yd = y.double().cpu()
+    assert rel_err(ps[0], yd.sum((0, 2, 3))) < 1e-3
+    assert rel_err(ps[1], (yd * yd).sum((0, 2, 3))) < 1e-4
+    # backward-data into a 4-element-offset view, then accumulating
+    dy = bf(torch.randn(B, Cout, Ho, Wo))
+    dyg = nhwc_bf16(dy, cpad=rup8(Cout))
+    want = F.conv_transpose2d(dy.double(), wq.double(), None, s, p,
+                              output_padding=(H + 2 * p - k - (Ho - 1) * s, W + 2 * p - k - (Wo - 1) * s))
+    ldx = Cin + 4
+    dxbuf = torch.full((B, H, W, ldx), 5.0, dtype=torch.bfloat16, device="cuda")
+    dxv = dxbuf.view(-1)[4:]
+    for acc, mult in ((0, 1), (1, 2)):
+        L.check(lib.yh_bf16_conv_bwd_data(dyg.data_ptr(), rup8(Cout), None, 0, wb.data_ptr(), ldb, dxv.data_ptr(), ldx, B, H, W, Cin,
+                                          rup8(Cout), k, s, acc, st), "bwd_data")
+        dx = dxbuf[..., 4:].float().permute(0, 3, 1, 2)
+        assert rel_err(dx, mult * want) < mult * BF16_OUT_TOL
+        assert bool((dxbuf[..., :4] == 5.0).all())
+
+
 def test_bf16_mfma_operand_maps_with_exact_integers():
     """A = I (through the conv: 1x1, weights = identity) and an ASYMMETRIC second operand, small integers that bf16 and
     fp32 hold exactly: any swapped row/column or k map gives a wrong integer, not a rounding difference."""
