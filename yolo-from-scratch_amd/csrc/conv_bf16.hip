@@ -139,12 +139,19 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     u32x4 raA[AROWS], rbA[BPASS], raB[AROWS], rbB[BPASS];
     // C64: per-thread constants of the B tile (which octet row / column each of the thread's pieces is)
     int bo[BPASS], bnn[BPASS];
+    unsigned boffb[BPASS];                   // C64: byte offset of each weight piece inside its 8-octet chunk row block
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) {
         const int e = t + 256 * p;
         bo[p] = e / BN;
         bnn[p] = n0 + (e - bo[p] * BN);
-        if (bo[p] >= 8 || bnn[p] >= g.ldw) bo[p] = 1 << 20;         // never valid
+        const int col = bnn[p] < g.ldw ? bnn[p] : g.ldw - 1;
+        boffb[p] = (unsigned)(bo[p] * g.ldw + col) * 16u;
+        if (bo[p] >= 8 || bnn[p] >= g.ldw) bo[p] = 1 << 20;         // never valid (general path)
+    }
+    if (C64) {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) roff[i] = (int)(((unsigned)roff[i] + 8u * (unsigned)kq) * 2u);   // bytes, this thread's octet folded in
     }
     // Every load is issued unconditionally: a piece that lies outside the image / past K reads a valid dummy address and
     // is zeroed when it is written to LDS (validity bits travel with the register set).  A load inside a branch cannot be
@@ -154,25 +161,30 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
     auto load_tiles = [&](int c, u32x4 (&ra)[AROWS], u32x4 (&rb)[BPASS], unsigned &mk) {
         unsigned m = 0;
         if (C64) {
+            // Per piece this path costs a bounds test, one 32-bit add and one select: offsets are unsigned BYTE offsets from a
+            // workgroup-uniform base (the tensors are < 2^31 elements, so they fit 32 bits and the load takes the scalar-base
+            // form: no 64-bit vector arithmetic), and the weight pieces need nothing at all -- K is a whole number of chunks and
+            // the column was clamped into the pack once (a clamped column only feeds output columns >= N, which are never
+            // stored or summed).  The PMC counters read 19 vector instructions per MFMA before this (SQ_INSTS_VALU 1383 per
+            // wave of a 64 -> 64 3x3 layer against 72 MFMAs): the loop was bound by instruction issue, not by LDS or the caches.
             const int k0 = c * BK;                                   // workgroup-uniform from here on
             const int tap = (int)__umulhi((unsigned)k0, g.cin_magic), ci0 = k0 - tap * g.Cin;
-            const int dy = tapt[tap], dx = tapt[9 + tap];
-            const int toff = (dy * g.Wi + dx) * g.ldi + ci0 + 8 * kq;
-            const bf16 *inb = (g.in2 && k0 >= g.ksplit) ? g.in2 - g.ksplit : g.in;
+            const int dy = __builtin_amdgcn_readfirstlane(tapt[tap]), dx = __builtin_amdgcn_readfirstlane(tapt[9 + tap]);
+            const bool second = g.in2 && k0 >= g.ksplit;
+            const unsigned char *inb = (const unsigned char *)(second ? g.in2 - g.ksplit : g.in);
+            const unsigned toffb = (unsigned)(((dy * g.Wi + dx) * g.ldi + ci0) * 2);      // added modulo 2^32 (may be "negative")
+            const unsigned dummy = second ? (unsigned)g.ksplit * 2u : 0u;                  // a readable address for masked rows
 #pragma unroll
             for (int i = 0; i < AROWS; ++i) {
                 const bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
                 m |= (unsigned)ok << i;
-                ra[i] = *(const u32x4 *)(ok ? inb + (roff[i] + toff) : g.in);
+                const unsigned off = ok ? (unsigned)roff[i] + toffb : dummy;              // roff holds BYTES (+ this thread's octet) here
+                ra[i] = *(const u32x4 *)(inb + off);
             }
-            const bf16 *wrow = g.w + ((size_t)(tapt[18 + tap] * cin8 + (ci0 >> 3)) * g.ldw << 3);
-            const int orem = (g.Ktot - k0) >> 3;                     // octet rows left in K (>= 8 except in a ragged last chunk)
+            const int tw = __builtin_amdgcn_readfirstlane(tapt[18 + tap]);                 // (an LDS read: tell the compiler it is uniform)
+            const unsigned char *wrow = (const unsigned char *)(g.w + ((size_t)(tw * cin8 + (ci0 >> 3)) * g.ldw << 3));
 #pragma unroll
-            for (int p = 0; p < BPASS; ++p) {
-                const bool ok = bo[p] < orem;
-                m |= (unsigned)ok << (8 + p);
-                rb[p] = *(const u32x4 *)(ok ? wrow + ((size_t)(bo[p] * g.ldw + bnn[p]) << 3) : g.w);
-            }
+            for (int p = 0; p < BPASS; ++p) rb[p] = *(const u32x4 *)(wrow + boffb[p]);
             mk = m;
             return;
         }
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
             const int e = t + 256 * p;          // < 8 BN for every piece: the tile is a whole number of passes
-            *(u32x4 *)(b + e * 16) = (mk >> (8 + p)) & 1u ? rb[p] : z;
+            *(u32x4 *)(b + e * 16) = (C64 || ((mk >> (8 + p)) & 1u)) ? rb[p] : z;
         }
     };
 
