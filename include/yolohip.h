@@ -331,12 +331,24 @@ int yh_candidates(const float *const pred[3], const float *anchors, const int gr
                   float conf_thr, float pad_left, float pad_top, float scale, float *boxes, float *scores,
                   int32_t *classes, int32_t *count, int cap, int32_t *ws, const float *letterbox_dev, void *stream);
 int64_t yh_candidates_ws(const int grid[3]);
-/* Class-aware greedy NMS = torchvision.ops.batched_nms as called at train.py:1232-1233: stable
- * descending score order, suppress IoU > thr within a class.  M is read from count[0] on the
- * device (clamped to cap).  keep (cap) int32 receives kept candidate indices in descending score
- * order, nkeep[0] their number.  ws: >= yh_nms_ws(cap) bytes. */
+/* torchvision.ops.batched_nms as called at train.py:1232-1233: stable descending score order (ties: lower candidate
+ * index first), greedy suppression of IoU > thr.  Both of torchvision's branches, selected by `mode`:
+ *   YH_NMS_PER_CLASS         _batched_nms_vanilla: suppression only between boxes of the same class;
+ *   YH_NMS_COORDINATE_TRICK  _batched_nms_coordinate_trick: boxes + float(class) * (boxes.max() + 1) in fp32 (one rounding
+ *                            per operation), then ONE class-agnostic NMS over the shifted boxes;
+ *   YH_NMS_TORCHVISION_CPU   torchvision's own rule for a CPU tensor -- the reference's CPU path, the parity target:
+ *                            4 M > 4000 -> per class, else coordinate trick (decided on the device from count[0]);
+ *   YH_NMS_TORCHVISION_CUDA  the same rule with torchvision's limit for GPU tensors (20000).
+ * iou_thr is a double like the `double iou_threshold` of torchvision's CPU kernel, which promotes the fp32 IoU for the
+ * comparison (thr = 0.4 suppresses an IoU of exactly float32(0.4)).  M is read from count[0] on the device (clamped to
+ * cap).  keep (cap) int32 receives kept candidate indices in descending score order, nkeep[0] their number.
+ * ws: >= yh_nms_ws(cap) bytes, 256-byte aligned. */
+#define YH_NMS_PER_CLASS 0
+#define YH_NMS_COORDINATE_TRICK 1
+#define YH_NMS_TORCHVISION_CPU 2
+#define YH_NMS_TORCHVISION_CUDA 3
 int yh_nms(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count, int cap,
-           float iou_thr, int32_t *keep, int32_t *nkeep, void *ws, void *stream);
+           double iou_thr, int mode, int32_t *keep, int32_t *nkeep, void *ws, void *stream);
 int64_t yh_nms_ws(int cap);
 
 /* ---- input side: label lists -> dense target grids --------------------------------- */

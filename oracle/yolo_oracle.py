@@ -8,11 +8,13 @@ package (``yolo-from-scratch_amd/``) never does.
 
 Pinning: every function here is checked against outputs of the reference itself (generated in the
 build container by ``tests/golden/make_golden.py`` and committed as ``tests/golden/*.npz``) in
-``tests/test_oracle_pinned.py``.  One piece is pinned only by definition: the class-aware NMS
-(`batched_nms`), because the reference delegates it to ``torchvision.ops.batched_nms``
+``tests/test_oracle_pinned.py``.  One piece cannot be pinned that way: the class-aware NMS
+(`nms_batched`), because the reference delegates it to ``torchvision.ops.batched_nms``
 (train.py:1232-1233), a third-party dependency that is not installed here and that the reference
-pins no version of (README.md:25).  For that step "parity unpinned" applies; it is anchored on the
-reference's own python ``nms`` (train.py:1086-1112) known-answer tests instead.
+pins no version of (README.md:25).  Its published algorithm is restated (BOTH branches and the size
+rule that picks one, see `nms_batched`); no output of torchvision itself is available in this image,
+so for that step "parity unpinned" applies; it is anchored on the reference's own python ``nms``
+(train.py:1086-1112) known-answer tests (single class, no threshold ties => identical selections).
 
 The model is written functionally: it walks the network graph reading tensors out of a flat
 ``{state_dict key: tensor}`` mapping, so the same code evaluates reference weights, product weights
@@ -271,19 +273,37 @@ def candidates(preds, anchors_list, img_size: int, num_classes: int, conf_thresh
     return torch.cat(boxes), torch.cat(scores), torch.cat(classes)
 
 
-def nms_batched(boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray, thr: float) -> np.ndarray:
-    """Class-aware greedy NMS = the contract of torchvision.ops.batched_nms as used at
-    train.py:1232-1233: stable sort by score descending (ties -> lower index
-    first); a box is suppressed by an earlier kept box of the SAME class when
-    inter / (area_i + area_j - inter) > thr, everything in fp32 with one rounding per operation.
-    Returns kept candidate indices in descending-score order (int64)."""
+# torchvision.ops.batched_nms, the call of train.py:1232-1233.  torchvision is a third-party dependency that is absent
+# from this image and that the reference pins no version of (README.md:25: "pip install torch torchvision"); what follows
+# restates its PUBLISHED algorithm (torchvision/ops/boxes.py: batched_nms, _batched_nms_coordinate_trick,
+# _batched_nms_vanilla; torchvision/csrc/ops/cpu/nms_kernel.cpp: nms_kernel_impl), unchanged since torchvision 0.9:
+#
+#   batched_nms(boxes, scores, idxs, thr):
+#       if boxes.numel() > (4000 if boxes.device.type == "cpu" else 20000): _batched_nms_vanilla
+#       else:                                                               _batched_nms_coordinate_trick
+#   _batched_nms_coordinate_trick: max_coordinate = boxes.max(); offsets = idxs.to(boxes) * (max_coordinate + 1);
+#       nms(boxes + offsets[:, None], scores, thr)            -- ONE class-agnostic nms over shifted boxes
+#   _batched_nms_vanilla: nms() per unique class; the union of the kept indices, sorted by score descending
+#   nms (CPU kernel): areas = (x2-x1)*(y2-y1); order = scores.sort(stable, descending); greedy scan, j is suppressed by
+#       a kept i when  inter / (area_i + area_j - inter) > thr  with inter = max(0, xx2-xx1) * max(0, yy2-yy1);
+#       boxes are scalar_t = float, every operation rounds to fp32, and `thr` is a C double: the fp32 IoU is PROMOTED
+#       to double for the comparison (so with thr = 0.4 an IoU of exactly float32(0.4) = 0.4000000059... IS suppressed).
+#
+# The reference's CPU path (the parity target) takes the coordinate trick for M <= 1000 candidates and the per-class
+# form above that.  The two differ for nc > 1: the shifted coordinates round on a coarser grid (ulp 0.004 at 5e4), and
+# boxes with negative coordinates of one class can reach into the previous class's band and suppress across classes.
+NMS_MODES = ("vanilla", "trick", "cpu", "cuda")   # "cpu"/"cuda" = torchvision's size rule for a tensor on that device
+
+
+def nms_plain(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
+    """torchvision.ops.nms, CPU kernel, fp32 boxes: kept indices in descending-score order (ties: lower index first)."""
     boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
     scores = np.asarray(scores, np.float32).reshape(-1)
-    classes = np.asarray(classes).reshape(-1)
+    thr = float(thr)                                              # C double in the kernel's signature
     order = np.argsort(-scores, kind="stable")
     x1, y1, x2, y2 = (boxes[:, k] for k in range(4))
-    area = ((x2 - x1).astype(np.float32) * (y2 - y1).astype(np.float32)).astype(np.float32)
-    thr32 = np.float32(thr)
+    with np.errstate(invalid="ignore", over="ignore"):
+        area = ((x2 - x1).astype(np.float32) * (y2 - y1).astype(np.float32)).astype(np.float32)
     dead = np.zeros(len(order), bool)
     kept = []
     for a, i in enumerate(order):
@@ -291,13 +311,49 @@ def nms_batched(boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray, thr:
             continue
         kept.append(int(i))
         rest = order[a + 1:]
-        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest])).astype(np.float32)
-        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest])).astype(np.float32)
-        inter = (w * h).astype(np.float32)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            iou = inter / ((area[i] + area[rest]).astype(np.float32) - inter).astype(np.float32)
-        dead[a + 1:] |= (iou > thr32) & (classes[rest] == classes[i])
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest])).astype(np.float32)
+            h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest])).astype(np.float32)
+            inter = (w * h).astype(np.float32)
+            iou = (inter / ((area[i] + area[rest]).astype(np.float32) - inter).astype(np.float32)).astype(np.float32)
+        dead[a + 1:] |= iou.astype(np.float64) > thr
     return np.asarray(kept, np.int64)
+
+
+def nms_shifted_boxes(boxes: np.ndarray, classes: np.ndarray) -> np.ndarray:
+    """boxes_for_nms of _batched_nms_coordinate_trick: three fp32 operations, one rounding each."""
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
+    with np.errstate(invalid="ignore", over="ignore"):
+        unit = np.float32(boxes.max() + np.float32(1))                                  # max_coordinate + tensor(1).to(boxes)
+        offsets = (np.asarray(classes).reshape(-1).astype(np.float32) * unit).astype(np.float32)   # idxs.to(boxes) * (...)
+        return (boxes + offsets[:, None]).astype(np.float32)
+
+
+def nms_uses_trick(num_boxes: int, mode: str) -> bool:
+    """torchvision's branch for M boxes: numel = 4 M against 4000 (CPU tensors) / 20000 (GPU tensors)."""
+    assert mode in NMS_MODES, mode
+    if mode in ("vanilla", "trick"):
+        return mode == "trick"
+    return not (4 * num_boxes > (4000 if mode == "cpu" else 20000))
+
+
+def nms_batched(boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray, thr: float, mode: str = "cpu") -> np.ndarray:
+    """torchvision.ops.batched_nms as the reference calls it (train.py:1232-1233).  mode "cpu" (default:
+    the reference's CPU path) / "cuda" apply torchvision's size rule, "vanilla" / "trick" force one branch.
+    Returns kept candidate indices in descending-score order (int64)."""
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
+    scores = np.asarray(scores, np.float32).reshape(-1)
+    classes = np.asarray(classes).reshape(-1).astype(np.int64)
+    if len(scores) == 0:
+        return np.zeros(0, np.int64)
+    if nms_uses_trick(len(scores), mode):
+        return nms_plain(nms_shifted_boxes(boxes, classes), scores, thr)
+    keep_mask = np.zeros(len(scores), bool)
+    for c in np.unique(classes):
+        cur = np.nonzero(classes == c)[0]
+        keep_mask[cur[nms_plain(boxes[cur], scores[cur], thr)]] = True
+    keep = np.nonzero(keep_mask)[0]
+    return keep[np.argsort(-scores[keep], kind="stable")].astype(np.int64)          # CPU torch.sort is a stable sort
 
 
 def iou_corners(a, b) -> float:

@@ -25,15 +25,23 @@ def _iou_f32(b, i, js):
     h = np.maximum(np.float32(0), np.minimum(y2[i], y2[js]) - np.maximum(y1[i], y1[js])).astype(np.float32)
     inter = (w * h).astype(np.float32)
     with np.errstate(divide="ignore", invalid="ignore"):
-        return (inter / ((area[i] + area[js]).astype(np.float32) - inter).astype(np.float32)).astype(np.float32)
+        iou = (inter / ((area[i] + area[js]).astype(np.float32) - inter).astype(np.float32)).astype(np.float32)
+    return iou.astype(np.float64)          # exact promotion: comparisons against the double threshold happen in double
 
 
-def explain_selection(boxes_a, scores_a, boxes_b, scores_b, classes, sel_a, thr, ulps=4, score_tol=1e-6):
+def explain_selection(boxes_a, scores_a, boxes_b, scores_b, classes, sel_a, thr, ulps=4, score_tol=1e-6, mode="cpu"):
+    """mode: the branch rule of torchvision.ops.batched_nms both selections were made with (oracle.nms_batched).  Under
+    the coordinate trick each evaluation is replayed on ITS OWN shifted boxes (its own boxes.max()) with no class test,
+    exactly what that branch computes; the threshold is compared as a double like torchvision's CPU kernel does."""
+    from oracle import yolo_oracle as orc
     boxes_a, boxes_b = np.asarray(boxes_a, np.float32), np.asarray(boxes_b, np.float32)
     scores_a, scores_b = np.asarray(scores_a, np.float32), np.asarray(scores_b, np.float32)
     classes = np.asarray(classes)
-    thr32 = np.float32(thr)
-    pad = np.float32(ulps) * np.spacing(thr32)
+    if len(scores_a) and orc.nms_uses_trick(len(scores_a), mode):
+        boxes_a, boxes_b = orc.nms_shifted_boxes(boxes_a, classes), orc.nms_shifted_boxes(boxes_b, classes)
+        classes = np.zeros_like(classes)
+    thr32 = float(thr)                                   # fp32 IoUs are promoted to double for every comparison below
+    pad = float(ulps) * float(np.spacing(np.float32(thr)))
     order = np.argsort(-scores_a, kind="stable")
     # order: inversions of B's scores along A's order must be near-ties
     sb = scores_b[order]
@@ -68,7 +76,7 @@ def explain_selection(boxes_a, scores_a, boxes_b, scores_b, classes, sel_a, thr,
     return ambiguous, swaps
 
 
-def explain_detections(det, hip_preds, ref_preds, anchors, img_size, nc, conf_thr, iou_thr, letterbox):
+def explain_detections(det, hip_preds, ref_preds, anchors, img_size, nc, conf_thr, iou_thr, letterbox, mode="cpu"):
     """Everything one image's post-process differs from the oracle pipeline by, accounted for (used by the inference-session
     and predict_batch tests).  det: the Detector after candidates + nms; hip_preds / ref_preds: the three (1,G,G,3,5+nc) head
     tensors of the HIP forward and of the oracle forward on the same image; letterbox = (pad_left, pad_top, scale).
@@ -82,7 +90,7 @@ def explain_detections(det, hip_preds, ref_preds, anchors, img_size, nc, conf_th
     M = int(det.count.item())
     gb, gs, gc = det.boxes[:M].cpu().numpy(), det.scores[:M].cpu().numpy(), det.classes[:M].cpu().numpy()
     got = det.keep[: int(det.nkeep.item())].cpu().numpy()
-    np.testing.assert_array_equal(got, orc.nms_batched(gb, gs, gc, iou_thr))                       # (a)
+    np.testing.assert_array_equal(got, orc.nms_batched(gb, gs, gc, iou_thr, mode))                 # (a)
     delta = max(float((a.cpu() - r).abs().max()) for a, r in zip(hip_preds, ref_preds))
     obj_ref = torch.cat([torch.sigmoid(p[0, ..., 4]).reshape(-1) for p in ref_preds])
     obj_hip = torch.cat([torch.sigmoid(p[0, ..., 4].cpu()).reshape(-1) for p in hip_preds])
@@ -96,9 +104,9 @@ def explain_detections(det, hip_preds, ref_preds, anchors, img_size, nc, conf_th
     same_cls = ac[cells].numpy() == gc
     assert int((~same_cls).sum()) <= max(1, M // 200)                                              # argmax over near-tied class logits
     ambiguous, swaps = explain_selection(gb, gs, ab[cells].numpy(), asx[cells].numpy(), gc, got, iou_thr, ulps=4,
-                                         score_tol=max(delta, 1e-6))                               # (c)
+                                         score_tol=max(delta, 1e-6), mode=mode)                    # (c)
     assert len(ambiguous) <= max(2, M // 100), ambiguous
     if not ambiguous and not swaps and not bool(differ.any()) and bool(same_cls.all()):
         b, s, c = orc.candidates(ref_preds, anchors, img_size, nc, conf_thr, *letterbox)
-        np.testing.assert_array_equal(got, orc.nms_batched(b.numpy(), s.numpy(), c.numpy(), iou_thr))
+        np.testing.assert_array_equal(got, orc.nms_batched(b.numpy(), s.numpy(), c.numpy(), iou_thr, mode))
     return int(differ.sum()), ambiguous

@@ -91,17 +91,51 @@ def _rand_boxes(M, seed, ncls, dup=False, spread=600.0):
     return boxes, scores, classes
 
 
+@pytest.mark.parametrize("mode", ["cpu", "vanilla", "trick", "cuda"])
 @pytest.mark.parametrize("M,ncls,dup,thr", [(0, 1, False, 0.4), (1, 1, False, 0.4), (3, 1, False, 0.5), (64, 1, False, 0.4),
-                                           (65, 3, True, 0.4), (129, 1, True, 0.6), (1000, 1, False, 0.4),
-                                           (1000, 80, True, 0.4), (4096, 3, True, 0.45), (4097, 1, False, 0.3),
-                                           (20000, 5, True, 0.4)])
-def test_nms_indices_bit_exact_vs_oracle(M, ncls, dup, thr):
+                                           (64, 3, True, 0.4), (64, 80, True, 0.4), (65, 3, True, 0.4), (129, 1, True, 0.6),
+                                           (1000, 1, False, 0.4), (1000, 3, True, 0.4), (1000, 80, True, 0.4),
+                                           (1001, 3, True, 0.4), (1001, 80, True, 0.4), (4096, 3, True, 0.45),
+                                           (4096, 80, True, 0.4), (4097, 1, False, 0.3), (5000, 80, True, 0.4),
+                                           (5001, 80, True, 0.4), (20000, 5, True, 0.4)])
+def test_nms_indices_bit_exact_vs_oracle(M, ncls, dup, thr, mode):
+    """Both branches of torchvision.ops.batched_nms and its size rule (M = 1000 / 1001 straddle the CPU limit of 4000
+    elements, 5000 / 5001 the GPU limit), boxes with negative coordinates, score ties, identical boxes."""
     y = api()
-    boxes, scores, classes = _rand_boxes(M, 1234 + M, ncls, dup, spread=300.0 if M <= 4097 else 2000.0)
-    want = orc.nms_batched(boxes, scores, classes, thr)
-    got = y.batched_nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(classes).cuda(), thr)
+    boxes, scores, classes = _rand_boxes(M, 1234 + M, ncls, dup, spread=300.0 if M <= 5001 else 2000.0)
+    boxes -= np.float32(30.0)                                     # negative coordinates: cross-class overlaps under the trick
+    want = orc.nms_batched(boxes, scores, classes, thr, mode)
+    got = y.batched_nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(classes).cuda(), thr, mode)
     assert got.dtype == torch.int64
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_nms_default_mode_is_the_reference_cpu_branch():
+    y = api()
+    for M in (1000, 1001):
+        boxes, scores, classes = _rand_boxes(M, 99 + M, 80, True, spread=300.0)
+        dflt = y.batched_nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(classes).cuda(), 0.4)
+        np.testing.assert_array_equal(dflt.cpu().numpy(), orc.nms_batched(boxes, scores, classes, 0.4, "trick" if M == 1000 else "vanilla"))
+
+
+def test_nms_branches_differ_where_torchvisions_do():
+    """Constructed nc > 1 inputs on which the coordinate trick and the per-class form select differently (the oracle test
+    of the same name explains them): the HIP path follows each branch, and the default follows the CPU rule (M <= 1000)."""
+    y = api()
+    s2 = torch.tensor([0.9, 0.8]).cuda()
+    b = torch.tensor([[600, 600, 640, 640], [-41, -41, -1, -1]], dtype=torch.float32).cuda()
+    c = torch.tensor([0, 1]).cuda()
+    assert y.batched_nms(b, s2, c, 0.4, "vanilla").tolist() == [0, 1]
+    assert y.batched_nms(b, s2, c, 0.4, "trick").tolist() == [0]
+    assert y.batched_nms(b, s2, c, 0.4).tolist() == [0]
+    b = torch.tensor([[303.3179016113281, 364.748291015625, 337.342529296875, 374.748291015625],
+                      [317.89996337890625, 364.748291015625, 351.92462158203125, 374.748291015625], [0, 0, 640, 1]],
+                     dtype=torch.float32).cuda()
+    s3, c3 = torch.tensor([0.9, 0.8, 0.1]).cuda(), torch.tensor([79, 79, 0]).cuda()
+    assert y.batched_nms(b, s3, c3, 0.4, "vanilla").tolist() == [0, 1, 2]
+    assert y.batched_nms(b, s3, c3, 0.4, "trick").tolist() == [0, 2]
+    with pytest.raises(ValueError):
+        y.batched_nms(b, s3, c3, 0.4, "fastest")
 
 
 def test_nms_threshold_edge_is_strict_greater():
@@ -111,8 +145,14 @@ def test_nms_threshold_edge_is_strict_greater():
     s = torch.tensor([0.9, 0.8]).cuda()
     c = torch.zeros(2, dtype=torch.int64).cuda()
     third = float(np.float32(50.0) / np.float32(150.0))
-    assert y.batched_nms(b, s, c, third).tolist() == [0, 1]                      # IoU == thr is kept
-    assert y.batched_nms(b, s, c, float(np.nextafter(np.float32(third), np.float32(0)))).tolist() == [0]
+    for mode in ("vanilla", "trick"):
+        assert y.batched_nms(b, s, c, third, mode).tolist() == [0, 1]                # IoU == thr is kept
+        assert y.batched_nms(b, s, c, float(np.nextafter(np.float32(third), np.float32(0))), mode).tolist() == [0]
+        # the threshold is a double (torchvision's CPU kernel promotes the fp32 IoU): inter 2 / union 5 = float32(0.4) > 0.4
+        b2 = torch.tensor([[0, 0, 3.5, 1], [1.5, 0, 5, 1]], dtype=torch.float32).cuda()
+        assert y.batched_nms(b2, s, c, 0.4, mode).tolist() == [0]
+        assert y.batched_nms(b2, s, c, float(np.float32(0.4)), mode).tolist() == [0, 1]
+        assert y.batched_nms(b2, s, c, float(np.nextafter(np.float32(0.4), np.float32(0))), mode).tolist() == [0]
 
 
 def test_nms_matches_reference_python_nms_known_answers():

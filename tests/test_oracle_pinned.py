@@ -162,6 +162,75 @@ def test_batched_nms_is_class_aware_and_stable():
     assert list(orc.nms_batched(np.zeros((0, 4)), np.zeros(0), np.zeros(0), 0.5)) == []
 
 
+def _nms_bruteforce(boxes, scores, thr):
+    """Independent scalar re-statement of torchvision's CPU nms loop (python floats rounded through np.float32)."""
+    f = np.float32
+    order = sorted(range(len(scores)), key=lambda k: (-float(scores[k]), k))
+    dead, kept = set(), []
+    for a, i in enumerate(order):
+        if i in dead:
+            continue
+        kept.append(i)
+        ai = f(f(boxes[i, 2] - boxes[i, 0]) * f(boxes[i, 3] - boxes[i, 1]))
+        for j in order[a + 1:]:
+            if j in dead:
+                continue
+            w = max(f(0), f(min(boxes[i, 2], boxes[j, 2]) - max(boxes[i, 0], boxes[j, 0])))
+            h = max(f(0), f(min(boxes[i, 3], boxes[j, 3]) - max(boxes[i, 1], boxes[j, 1])))
+            inter = f(w * h)
+            aj = f(f(boxes[j, 2] - boxes[j, 0]) * f(boxes[j, 3] - boxes[j, 1]))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ovr = f(inter / f(f(ai + aj) - inter))
+            if float(ovr) > thr:
+                dead.add(j)
+    return kept
+
+
+def test_batched_nms_both_torchvision_branches():
+    """The two branches of torchvision.ops.batched_nms and the size rule that picks one (oracle header).  Unpinned by the
+    reference; held here to an independent scalar restatement and to constructed cases whose answer is known by hand."""
+    rng = np.random.default_rng(7)
+    for M, nc in ((40, 3), (200, 80), (300, 5)):
+        ctr, wh = rng.uniform(-20, 300, (M, 2)), rng.uniform(8, 120, (M, 2))
+        b = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+        sc = rng.uniform(0.01, 1, M).astype(np.float32)
+        sc[rng.integers(0, M, M // 4)] = sc[rng.integers(0, M, M // 4)]
+        cl = rng.integers(0, nc, M)
+        shifted = orc.nms_shifted_boxes(b, cl)
+        unit = np.float32(b.max() + np.float32(1))
+        np.testing.assert_array_equal(shifted, (b + (cl.astype(np.float32) * unit).astype(np.float32)[:, None]).astype(np.float32))
+        assert list(orc.nms_batched(b, sc, cl, 0.4, "trick")) == _nms_bruteforce(shifted, sc, 0.4)
+        per_class = []
+        for c in np.unique(cl):
+            idx = np.nonzero(cl == c)[0]
+            per_class += [int(idx[k]) for k in _nms_bruteforce(b[idx], sc[idx], 0.4)]
+        per_class.sort(key=lambda k: (-float(sc[k]), k))
+        assert list(orc.nms_batched(b, sc, cl, 0.4, "vanilla")) == per_class
+        assert list(orc.nms_batched(b, sc, cl, 0.4)) == list(orc.nms_batched(b, sc, cl, 0.4, "trick"))   # M <= 1000: trick
+        z = np.zeros(M, np.int64)                                                 # one class: offsets are 0, branches agree
+        assert list(orc.nms_batched(b, sc, z, 0.4, "trick")) == list(orc.nms_batched(b, sc, z, 0.4, "vanilla"))
+    # size rule: numel = 4 M, > 4000 (CPU tensors) / > 20000 (GPU tensors) -> per class
+    assert orc.nms_uses_trick(1000, "cpu") and not orc.nms_uses_trick(1001, "cpu")
+    assert orc.nms_uses_trick(5000, "cuda") and not orc.nms_uses_trick(5001, "cuda")
+    # the threshold is a C double: an IoU of exactly float32(0.4) = 0.4000000059... is above 0.4
+    b = np.array([[0, 0, 3.5, 1], [1.5, 0, 5, 1]], np.float32)                    # inter 2, union 5
+    s2 = np.array([0.9, 0.8], np.float32)
+    for mode in ("vanilla", "trick"):
+        assert list(orc.nms_batched(b, s2, [0, 0], 0.4, mode)) == [0]
+        assert list(orc.nms_batched(b, s2, [0, 0], float(np.float32(0.4)), mode)) == [0, 1]
+    # the branches DIFFER for nc > 1: (i) negative coordinates reach into the previous class's band ...
+    b = np.array([[600, 600, 640, 640], [-41, -41, -1, -1]], np.float32)          # class 1 shifted by 641 lands on class 0's box
+    assert list(orc.nms_batched(b, s2, [0, 1], 0.4, "vanilla")) == [0, 1]
+    assert list(orc.nms_batched(b, s2, [0, 1], 0.4, "trick")) == [0]
+    # ... (ii) the shifted coordinates round on a coarser grid (ulp 0.004 at 79 * 641): a pair just below the threshold
+    # unshifted is above it after the shift (found by search, values are exact float32)
+    b = np.array([[303.3179016113281, 364.748291015625, 337.342529296875, 374.748291015625],
+                  [317.89996337890625, 364.748291015625, 351.92462158203125, 374.748291015625], [0, 0, 640, 1]], np.float32)
+    s3, c3 = np.array([0.9, 0.8, 0.1], np.float32), np.array([79, 79, 0])
+    assert list(orc.nms_batched(b, s3, c3, 0.4, "vanilla")) == [0, 1, 2]
+    assert list(orc.nms_batched(b, s3, c3, 0.4, "trick")) == [0, 2]
+
+
 # ---- F8: candidate extraction --------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["nc1_sq", "nc3_rect"])
 def test_candidates_match_reference_predict(tag):

@@ -3,7 +3,15 @@
 // NMS index selection must match the CPU definition bit for bit, so this file is compiled with
 // floating-point contraction OFF (no FMA fusion): IoU is evaluated as
 //   inter / ((area_i + area_j) - inter) > thr      with area = (x2-x1)*(y2-y1),
-// one IEEE rounding per operation, exactly as torchvision's CPU kernel does.
+// one IEEE rounding per operation, exactly as torchvision's CPU kernel does; that kernel takes `thr` as a C double and
+// promotes the fp32 IoU for the comparison, which is the same as comparing against the largest float <= thr (host side).
+//
+// torchvision.ops.batched_nms (train.py:1232-1233) has TWO branches and both are here (yh_nms `mode`):
+//   per class ("vanilla", numel > 4000 on CPU tensors / > 20000 on GPU tensors): suppression only inside a class;
+//   coordinate trick (otherwise): every box is shifted by float(class) * (max coordinate + 1) -- three fp32 operations,
+//   each rounded -- and ONE class-agnostic NMS runs over the shifted boxes (areas and intersections of the SHIFTED
+//   coordinates, boxes of different classes may meet when coordinates are negative).  The branch is picked on the device
+//   from the candidate count, like everything else here.
 //
 // Pipeline (all sizes are device-side: M is read from count[0], launches are sized by `cap`):
 //   1. keys = (descending-orderable score, candidate index), all distinct -> position in the sorted order = number of
@@ -118,11 +126,23 @@ __device__ __forceinline__ uint64_t make_key(float score, int idx) {
     return ((uint64_t)(~u) << 32) | (uint32_t)idx;    // ascending key = descending score, then index
 }
 
+// torchvision's branch rule, evaluated on the device-side candidate count (numel = 4 M)
+__device__ __forceinline__ bool nms_uses_trick(int mode, int M) {
+    if (mode == YH_NMS_PER_CLASS) return false;
+    if (mode == YH_NMS_COORDINATE_TRICK) return true;
+    return !(4 * (int64_t)M > (mode == YH_NMS_TORCHVISION_CPU ? 4000 : 20000));
+}
+
+// torch.max semantics: a NaN operand wins
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); }
+
 struct NmsArgs {
     const float *boxes, *scores;
     const int32_t *classes, *count;
     int cap, W;                 // W = words per mask row = ceil(cap/64)
-    float thr;
+    float thr;                  // largest float <= the caller's double threshold
+    int mode;                   // YH_NMS_*
+    float *pmax;                // [ceil(cap/64)] per-workgroup maximum coordinate (coordinate trick)
     float *sboxes;              // [cap][4]
     int32_t *sclasses, *order;  // [cap]
     uint64_t *mask;             // [cap][W]
@@ -156,11 +176,18 @@ __global__ __launch_bounds__(64) void nms_rank_kernel(const NmsArgs a) {
             rank += (k2[0] < mine ? 1 : 0) + (k2[1] < mine ? 1 : 0);
         }
     }
+    float cmax = -INFINITY;
     if (i < M) {
         a.order[rank] = i;
         a.sclasses[rank] = a.classes[i];
-        *(f32x4 *)(a.sboxes + 4 * rank) = *(const f32x4 *)(a.boxes + 4 * i);
+        const f32x4 b = *(const f32x4 *)(a.boxes + 4 * i);
+        *(f32x4 *)(a.sboxes + 4 * rank) = b;
+        cmax = max_nan(max_nan(b[0], b[1]), max_nan(b[2], b[3]));
     }
+    // boxes.max() of the coordinate trick: this workgroup's share (max is exact, so any reduction order gives the same bits)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cmax = max_nan(cmax, __shfl_xor(cmax, o));
+    if (threadIdx.x == 0) a.pmax[blockIdx.x] = cmax;
 }
 
 // 64 x 64 blocks of the suppression bit matrix, upper triangle only (row block <= column block); a fixed grid of
@@ -173,6 +200,15 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
     __shared__ float cbx[64][4];
     __shared__ int ccl[64];
     const int t = threadIdx.x;
+    const bool trick = nms_uses_trick(a.mode, M);
+    float unit = 0.f;                                     // max_coordinate + 1 (fp32), the per-class shift unit
+    if (trick && blockIdx.x < npairs) {
+        float m = -INFINITY;
+        for (int j = t; j < nw; j += 64) m = max_nan(m, a.pmax[j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max_nan(m, __shfl_xor(m, o));
+        unit = m + 1.0f;
+    }
     for (int p = blockIdx.x; p < npairs; p += gridDim.x) {
         // p -> (rb, cb), rb <= cb: row rb starts at rb * nw - rb (rb - 1) / 2
         int rb = (int)(((2.0f * nw + 1.0f) - sqrtf((2.0f * nw + 1.0f) * (2.0f * nw + 1.0f) - 8.0f * (float)p)) * 0.5f);
@@ -184,14 +220,25 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
         const int cj = cb * 64 + t;
         __syncthreads();
         if (cj < M) {
-            *(f32x4 *)cbx[t] = *(const f32x4 *)(a.sboxes + 4 * cj);
-            ccl[t] = a.sclasses[cj];
+            f32x4 bj = *(const f32x4 *)(a.sboxes + 4 * cj);
+            const int cl = a.sclasses[cj];
+            if (trick) {                                   // boxes + offsets[:, None], offsets = idxs.to(boxes) * unit
+                const float off = (float)cl * unit;
+                bj[0] = bj[0] + off; bj[1] = bj[1] + off; bj[2] = bj[2] + off; bj[3] = bj[3] + off;
+            }
+            *(f32x4 *)cbx[t] = bj;
+            ccl[t] = trick ? 0 : cl;
         }
         __syncthreads();
         const int i = rb * 64 + t;
         if (i >= M) continue;
         f32x4 bi = *(const f32x4 *)(a.sboxes + 4 * i);
-        const int ci = a.sclasses[i];
+        int ci = a.sclasses[i];
+        if (trick) {
+            const float off = (float)ci * unit;
+            bi[0] = bi[0] + off; bi[1] = bi[1] + off; bi[2] = bi[2] + off; bi[3] = bi[3] + off;
+            ci = 0;
+        }
         const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
         uint64_t bits = 0;
         int ncol = M - cb * 64;
@@ -367,22 +414,28 @@ extern "C" int64_t yh_nms_ws(int cap) {
     size_t W = (size_t)(cap + 63) / 64;
     size_t b = align_up((size_t)cap * 16, 256);           // sorted boxes
     b += 2 * align_up((size_t)cap * 4, 256);              // sorted classes, order
+    b += align_up(W * 4, 256);                            // per-workgroup coordinate maxima
     b += align_up((size_t)cap * W * 8, 256);              // suppression bit matrix
     return (int64_t)b;
 }
 
 extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count, int cap,
-                      float iou_thr, int32_t *keep, int32_t *nkeep, void *ws, void *stream) {
+                      double iou_thr, int mode, int32_t *keep, int32_t *nkeep, void *ws, void *stream) {
     YH_REQUIRE(boxes && scores && classes && count && keep && nkeep && ws && cap > 0, "nms: bad argument");
+    YH_REQUIRE(mode >= YH_NMS_PER_CLASS && mode <= YH_NMS_TORCHVISION_CUDA, "nms: unknown mode %d", mode);
     YH_REQUIRE(cap <= 64 * kMaxWords, "nms: capacity %d above the supported %d", cap, 64 * kMaxWords);
     YH_REQUIRE(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)ws & 255) == 0, "nms: boxes 16-byte / workspace 256-byte alignment");
     NmsArgs a{};
     a.boxes = boxes; a.scores = scores; a.classes = classes; a.count = count;
-    a.cap = cap; a.W = (cap + 63) / 64; a.thr = iou_thr; a.keep = keep; a.nkeep = nkeep;
+    a.cap = cap; a.W = (cap + 63) / 64; a.keep = keep; a.nkeep = nkeep; a.mode = mode;
+    // (double)iou > thr  <=>  iou > (largest float <= thr): the CPU kernel's promoted comparison, done in fp32
+    a.thr = (float)iou_thr;
+    if ((double)a.thr > iou_thr) a.thr = nextafterf(a.thr, -INFINITY);
     char *p = (char *)ws;
     a.sboxes = (float *)p;    p += align_up((size_t)cap * 16, 256);
     a.sclasses = (int32_t *)p; p += align_up((size_t)cap * 4, 256);
     a.order = (int32_t *)p;   p += align_up((size_t)cap * 4, 256);
+    a.pmax = (float *)p;      p += align_up((size_t)a.W * 4, 256);
     a.mask = (uint64_t *)p;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(cap, 64)), dim3(64), 0, st, a);

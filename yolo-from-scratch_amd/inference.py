@@ -17,6 +17,20 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+# torchvision.ops.batched_nms has two branches (include/yolohip.h, yh_nms).  "cpu" = torchvision's size rule for CPU
+# tensors, i.e. what the reference's CPU path -- the parity target -- executes: coordinate trick for M <= 1000 candidates,
+# per class above; "cuda" = the rule torchvision applies to GPU tensors (limit 20000 elements); the other two force a branch.
+NMS_MODES = {"per_class": 0, "vanilla": 0, "coordinate_trick": 1, "trick": 1, "cpu": 2, "cuda": 3}
+DEFAULT_NMS_MODE = "cpu"
+
+
+def _nms_mode(mode) -> int:
+    try:
+        return NMS_MODES[mode]
+    except KeyError:
+        raise ValueError(f"nms mode {mode!r}: expected one of {sorted(NMS_MODES)}") from None
+
+
 class Detector:
     """Fixed-capacity device buffers + the two kernels of the post-process.  Everything stays on the
     device until `fetch`; capacity = every cell of the three grids, so nothing is ever truncated."""
@@ -53,9 +67,9 @@ class Detector:
                                       letterbox_dev.data_ptr() if letterbox_dev is not None else None,
                                       _stream(self.device)), "candidates")
 
-    def nms(self, iou_threshold: float):
+    def nms(self, iou_threshold: float, mode: str = DEFAULT_NMS_MODE):
         L.check(L.lib().yh_nms(self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr(),
-                               self.count.data_ptr(), self.cap, float(iou_threshold), self.keep.data_ptr(),
+                               self.count.data_ptr(), self.cap, float(iou_threshold), _nms_mode(mode), self.keep.data_ptr(),
                                self.nkeep.data_ptr(), self.ws_n.data_ptr(), _stream(self.device)), "nms")
 
     def fetch(self) -> List[Tuple[float, float, float, float, float, int]]:
@@ -69,9 +83,13 @@ class Detector:
         return [(bb[0], bb[1], bb[2], bb[3], ss, int(cc)) for bb, ss, cc in zip(b, s, c)]
 
 
-def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
-    """Same contract as torchvision.ops.batched_nms (the reference's call, train.py:1232-1233): kept
-    indices (int64) in descending-score order, suppression only within a class, IoU > threshold."""
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float,
+                mode: str = DEFAULT_NMS_MODE) -> torch.Tensor:
+    """Same contract as torchvision.ops.batched_nms (the reference's call, train.py:1232-1233): kept indices (int64) in
+    descending-score order, IoU > threshold suppresses (threshold compared as a double, like torchvision's CPU kernel).
+    `mode` picks torchvision's branch: "cpu" (default) applies its size rule for CPU tensors -- the reference's CPU path:
+    coordinate trick for boxes.numel() <= 4000, per class above --, "cuda" its rule for GPU tensors (20000),
+    "trick" / "vanilla" force one."""
     if not boxes.is_cuda:
         raise RuntimeError("batched_nms: the HIP path needs GPU tensors; no CPU fallback in this package")
     M = int(boxes.shape[0])
@@ -86,13 +104,14 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, i
     nkeep = torch.zeros(1, device=dev, dtype=torch.int32)
     ws = torch.empty(int(L.lib().yh_nms_ws(M)) + 256, device=dev, dtype=torch.uint8)
     L.check(L.lib().yh_nms(b.data_ptr(), s.data_ptr(), c.data_ptr(), count.data_ptr(), M, float(iou_threshold),
-                           keep.data_ptr(), nkeep.data_ptr(), ws.data_ptr(), _stream(dev)), "nms")
+                           _nms_mode(mode), keep.data_ptr(), nkeep.data_ptr(), ws.data_ptr(), _stream(dev)), "nms")
     return keep[: int(nkeep.item())].long()
 
 
-def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_threshold=0.4):
+def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_threshold=0.4, nms_mode=DEFAULT_NMS_MODE):
     """Letterbox -> model (eval) -> decode/threshold -> un-letterbox -> global class-aware NMS; returns
-    [(x1,y1,x2,y2,conf,class_id)] in original-image pixels (train.py:1114-1250)."""
+    [(x1,y1,x2,y2,conf,class_id)] in original-image pixels (train.py:1114-1250).  The NMS takes the branch of
+    torchvision.ops.batched_nms that the reference's CPU path takes for the same number of candidates (`nms_mode`)."""
     from PIL import Image
     model.eval()
     pil = Image.open(image_path).convert("RGB")
@@ -107,11 +126,11 @@ def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_th
         det = Detector(grids, num_classes, preds[0].device)
         model._detector = det
     det.candidates(preds, model.anchors, img_size, conf_threshold, pad_left, pad_top, scale)
-    det.nms(iou_threshold)
+    det.nms(iou_threshold, nms_mode)
     return det.fetch()
 
 
-def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_threshold=0.4):
+def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_threshold=0.4, nms_mode=DEFAULT_NMS_MODE):
     """`predict` for several images at once: ONE batched forward, then candidate extraction and
     class-aware NMS per image segment (each image keeps its own letterbox parameters and its own candidate set, so
     nothing is suppressed across images); one host synchronisation at the end.  `images`: paths or PIL images.
@@ -138,7 +157,7 @@ def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_
         model._detectors = dets
     for b, (pad_left, pad_top, scale) in enumerate(meta):
         dets[b].candidates([p[b:b + 1] for p in preds], model.anchors, S, conf_threshold, pad_left, pad_top, scale)
-        dets[b].nms(iou_threshold)
+        dets[b].nms(iou_threshold, nms_mode)
     return [dets[b].fetch() for b in range(len(xs))]
 
 
@@ -148,13 +167,14 @@ class InferenceSession:
     stream) and replayed per image.  Everything the graph touches has a fixed address: the input image,
     the letterbox parameters {pad_left, pad_top, scale} and all outputs live in static device buffers."""
 
-    def __init__(self, model, conf_threshold=0.5, iou_threshold=0.4, use_graph=True):
+    def __init__(self, model, conf_threshold=0.5, iou_threshold=0.4, use_graph=True, nms_mode=DEFAULT_NMS_MODE):
         self.model = model.eval()
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("InferenceSession: the HIP path needs the model on the GPU; no CPU fallback in this package")
         self.device, self.S, self.nc = p0.device, model.img_size, model.num_classes
-        self.conf, self.iou = float(conf_threshold), float(iou_threshold)
+        self.conf, self.iou, self.nms_mode = float(conf_threshold), float(iou_threshold), nms_mode
+        _nms_mode(nms_mode)
         self.x = torch.zeros(1, 3, self.S, self.S, device=self.device)
         self.lb = torch.tensor([0.0, 0.0, 1.0], device=self.device)
         self.use_graph = bool(use_graph)
@@ -193,7 +213,7 @@ class InferenceSession:
         L.run_ops(self.plan.fwd_ops[0], self.plan.fwd_ops[1], _stream(self.device), self.plan._ctx())
         preds = [v.buf.data.view(1, v.H, v.W, 3, v.C // 3) for v in self.heads]
         self.det.candidates(preds, self.model.anchors, self.S, self.conf, letterbox_dev=self.lb)
-        self.det.nms(self.iou)
+        self.det.nms(self.iou, self.nms_mode)
 
     def run(self, img: torch.Tensor, pad_left=0.0, pad_top=0.0, scale=1.0, fetch=True):
         """img: (1,3,S,S) or (3,S,S) float tensor (host or device).  Returns the detections list."""
