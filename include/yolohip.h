@@ -350,6 +350,11 @@ int64_t yh_candidates_ws(const int grid[3]);
 int yh_nms(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count, int cap,
            double iou_thr, int mode, int32_t *keep, int32_t *nkeep, void *ws, void *stream);
 int64_t yh_nms_ws(int cap);
+/* The result list of predict() (train.py:1236-1246) as one dense device table, so the host needs ONE copy: out[0], out[1]
+ * (int32 bits) = count[0], min(nkeep[0], cap); out[8 + 6 k ...] = x1, y1, x2, y2, score, class (int32 bits) of the k-th
+ * kept candidate in NMS order.  out: >= 8 + 6 * cap 32-bit words. */
+int yh_gather_detections(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count,
+                         const int32_t *keep, const int32_t *nkeep, int cap, float *out, void *stream);
 
 /* ---- input side: label lists -> dense target grids --------------------------------- */
 /* labels: DEVICE double [B][maxn][5] = (class, xc, yc, w, h) normalised to the padded square image, nlabels:

@@ -13,6 +13,7 @@ from .hostside import (nms, compute_iou_corners, compute_box_iou, get_lr_lambda,
                        yolo_collate_fn, compute_optimal_anchors, YOLO_SIZES, stack_targets, synthetic_targets,
                        save_checkpoint, load_checkpoint, raw_collate_fn)
 from .pipeline import DevicePrefetcher
+from .graph import invalidate_folded_weights
 
 __all__ = [
     "YOLO", "ConvBlock", "C3", "Bottleneck", "SPPF", "ciou_loss", "decode_predictions", "yolo_loss",
@@ -20,5 +21,5 @@ __all__ = [
     "HipTrainer", "nms", "compute_iou_corners", "compute_box_iou", "get_lr_lambda", "letterbox_resize",
     "YOLODataset", "yolo_collate_fn", "compute_optimal_anchors", "YOLO_SIZES", "stack_targets", "load_library",
     "LIB_PATH", "DEFAULT_ANCHORS", "synthetic_targets", "save_checkpoint", "load_checkpoint", "raw_collate_fn",
-    "DevicePrefetcher",
+    "DevicePrefetcher", "invalidate_folded_weights",
 ]

@@ -135,6 +135,7 @@ _SIGS = {
     "yh_assign_targets": (i32, [c_fp, c_fp, i32, i32, C.POINTER(f32), _IP, i32, i32, _PP, c_fp]),
     "yh_nms": (i32, [c_fp, c_fp, c_fp, c_fp, i32, C.c_double, i32, c_fp, c_fp, c_fp, c_fp]),
     "yh_nms_ws": (i64, [i32]),
+    "yh_gather_detections": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp]),
     "yh_grad_sqnorm": (i32, [c_fp, i64, f32, c_fp, c_fp, c_fp]),
     "yh_sqnorm_ws": (i64, [i64]),
     "yh_adam_step": (i32, [c_fp, c_fp, c_fp, c_fp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, c_fp, f32, c_fp]),

@@ -314,6 +314,29 @@ __global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) 
     if (t == 0) a.nkeep[0] = nk_sh;
 }
 
+// Kept detections as one dense table: header {count, nkeep} + nkeep rows (x1, y1, x2, y2, score, class bits) in NMS order,
+// so the host reads the result of predict() with ONE device->host copy (train.py:1236-1246 gathers boxes / scores /
+// classes with three indexed reads and one .item() per scalar).
+__global__ void gather_detections_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                         const int32_t *__restrict__ classes, const int32_t *__restrict__ count,
+                                         const int32_t *__restrict__ keep, const int32_t *__restrict__ nkeep, int cap,
+                                         float *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = nkeep[0];
+    if (n > cap) n = cap;
+    if (k == 0) {
+        ((int32_t *)out)[0] = count[0];
+        ((int32_t *)out)[1] = n;
+    }
+    if (k >= n) return;
+    const int i = keep[k];
+    const f32x4 b = *(const f32x4 *)(boxes + 4 * i);
+    float *r = out + 8 + 6 * (size_t)k;
+    r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; r[3] = b[3];
+    r[4] = scores[i];
+    r[5] = __int_as_float(classes[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Target assignment of YOLODataset.__getitem__ (train.py:164-205) on the device: one thread per image walks
 // its labels IN ORDER (first writer wins), so the result is identical to the sequential host rule.
@@ -445,6 +468,16 @@ extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *cl
     YH_CHECK_LAUNCH("nms_mask");
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kNmsThreads), 0, st, a);
     YH_CHECK_LAUNCH("nms_scan");
+    return 0;
+}
+
+extern "C" int yh_gather_detections(const float *boxes, const float *scores, const int32_t *classes, const int32_t *count,
+                                    const int32_t *keep, const int32_t *nkeep, int cap, float *out, void *stream) {
+    YH_REQUIRE(boxes && scores && classes && count && keep && nkeep && out && cap > 0, "gather_detections: bad argument");
+    YH_REQUIRE(((uintptr_t)boxes & 15) == 0, "gather_detections: boxes must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_detections_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, (hipStream_t)stream, boxes, scores,
+                       classes, count, keep, nkeep, cap, out);
+    YH_CHECK_LAUNCH("gather_detections");
     return 0;
 }
 

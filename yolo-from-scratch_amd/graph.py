@@ -26,6 +26,23 @@ from . import _lib as L
 BN_EPS_DEFAULT = 1e-5
 # bumped whenever this package's kernels modify parameters or BatchNorm buffers in place (see Plan.weights_state)
 WEIGHTS_EPOCH = [0]
+# bumped whenever this package moves parameter / buffer STORAGE (HipTrainer adopting the parameters into its flat buffer,
+# Module._apply: .to() / .cuda() / .float(), load_state_dict): plans and captured hipGraphs hold raw addresses
+PARAM_GENERATION = [0]
+
+
+def invalidate_folded_weights():
+    """Tell every eval plan / InferenceSession that parameter or BatchNorm-buffer VALUES changed behind torch's version
+    counters.  The package calls this itself wherever its own code writes parameter storage (optimizer kernels, training
+    forwards, HipTrainer's broadcast, load_state_dict); user code must call it after writes torch cannot see on the
+    registered tensors: `p.data.mul_()` / `p.data.copy_()` (`.data` carries its own version counter -- the usual EMA idiom),
+    writes through an aliasing view such as `trainer.flat_p`, and in-place collectives on parameters."""
+    WEIGHTS_EPOCH[0] += 1
+
+
+def state_token():
+    """One cheap comparison for 'nothing this package knows of has touched the weights or their addresses'."""
+    return (WEIGHTS_EPOCH[0], PARAM_GENERATION[0])
 
 
 def _rup4(c: int) -> int:
@@ -918,6 +935,12 @@ class Plan:
             if t is not None:
                 v += t._version
         return (WEIGHTS_EPOCH[0], v)
+
+    def fold_inputs(self) -> List[torch.Tensor]:
+        """The tensors the fold reads, resolved once (InferenceSession sums their version counters per image without
+        walking the module tree; a re-assigned attribute shows up as a PARAM_GENERATION / signature change instead)."""
+        self.weights_state()
+        return [t for t in (getattr(o, a) for o, a in self._fold_tensors) if t is not None]
 
     def refresh_folded_weights(self, stream: int) -> bool:
         """Eval plans: (re)fold BatchNorm into the packed weights when the weights changed since the last fold."""

@@ -10,6 +10,7 @@ import torch
 
 from . import _lib as L
 from .functional import _anchors18
+from .graph import state_token
 from .hostside import letterbox_resize
 
 
@@ -35,7 +36,8 @@ class Detector:
     """Fixed-capacity device buffers + the two kernels of the post-process.  Everything stays on the
     device until `fetch`; capacity = every cell of the three grids, so nothing is ever truncated."""
 
-    def __init__(self, grids: Sequence[int], num_classes: int, device, nms_workspace: torch.Tensor = None):
+    def __init__(self, grids: Sequence[int], num_classes: int, device, nms_workspace: torch.Tensor = None,
+                 max_fetch: int = 2048):
         """nms_workspace: a suppression-matrix scratch shared with other Detectors whose calls run in order on
         one stream (predict_batch): it is cap * ceil(cap/64) * 8 bytes (79 MB at 640x640, 1.27 GB at 1280)."""
         L.lib()
@@ -54,6 +56,12 @@ class Detector:
                                           or nms_workspace.dtype != torch.uint8):
             raise ValueError("nms_workspace too small / wrong device or dtype")
         self.ws_n = nms_workspace if nms_workspace is not None else torch.empty(need, device=device, dtype=torch.uint8)
+        # the result table of yh_gather_detections and its pinned host mirror: header + the first `max_fetch` rows arrive
+        # with ONE device->host copy (a longer list takes a second copy of the remaining rows)
+        self.max_fetch = min(self.cap, int(max_fetch))
+        self.out = torch.zeros(8 + 6 * self.cap, device=device, dtype=torch.float32)
+        self.out_pin = torch.zeros(8 + 6 * self.max_fetch, dtype=torch.float32).pin_memory()
+        self._out_np = self.out_pin.numpy()
 
     def candidates(self, preds: Sequence[torch.Tensor], anchors_list, img_size, conf_threshold, pad_left=0.0,
                    pad_top=0.0, scale=1.0, letterbox_dev: torch.Tensor = None):
@@ -72,15 +80,31 @@ class Detector:
                                self.count.data_ptr(), self.cap, float(iou_threshold), _nms_mode(mode), self.keep.data_ptr(),
                                self.nkeep.data_ptr(), self.ws_n.data_ptr(), _stream(self.device)), "nms")
 
-    def fetch(self) -> List[Tuple[float, float, float, float, float, int]]:
-        m, k = int(self.count.item()), int(self.nkeep.item())
+    def gather(self):
+        """Enqueue the result table (yh_gather_detections) and its copy into the pinned mirror; no host sync."""
+        L.check(L.lib().yh_gather_detections(self.boxes.data_ptr(), self.scores.data_ptr(), self.classes.data_ptr(),
+                                             self.count.data_ptr(), self.keep.data_ptr(), self.nkeep.data_ptr(), self.cap,
+                                             self.out.data_ptr(), _stream(self.device)), "gather_detections")
+        self.out_pin.copy_(self.out[: self.out_pin.numel()], non_blocking=True)
+
+    def read(self) -> List[Tuple[float, float, float, float, float, int]]:
+        """Wait for the stream and turn the pinned table into the reference's list of 6-tuples (train.py:1242-1246)."""
+        torch.cuda.current_stream(self.device).synchronize()
+        hdr = self._out_np[:2].view(np.int32)
+        m, k = int(hdr[0]), int(hdr[1])
         if m > self.cap:
             raise RuntimeError("candidate capacity exceeded")
-        idx = self.keep[:k].long()
-        b = self.boxes[idx].cpu().tolist()
-        s = self.scores[idx].cpu().tolist()
-        c = self.classes[idx].cpu().tolist()
-        return [(bb[0], bb[1], bb[2], bb[3], ss, int(cc)) for bb, ss, cc in zip(b, s, c)]
+        if k <= self.max_fetch:
+            rows = self._out_np[8: 8 + 6 * k].copy()
+        else:
+            rows = self.out[8: 8 + 6 * k].cpu().numpy()
+        rows = rows.reshape(k, 6)
+        cls = rows[:, 5].copy().view(np.int32).tolist()
+        return [(r[0], r[1], r[2], r[3], r[4], c) for r, c in zip(rows.tolist(), cls)]
+
+    def fetch(self) -> List[Tuple[float, float, float, float, float, int]]:
+        self.gather()
+        return self.read()
 
 
 def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float,
@@ -117,7 +141,7 @@ def predict(model, image_path, device, num_classes=1, conf_threshold=0.5, iou_th
     pil = Image.open(image_path).convert("RGB")
     img_size = model.img_size
     pil, scale, pad_top, pad_left = letterbox_resize(pil, img_size)
-    x = (torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0).unsqueeze(0).to(device)
+    x = torch.from_numpy(np.array(pil)).unsqueeze(0).to(device)     # (1,S,S,3) uint8: the /255 of train.py:1137 runs on the device
     with torch.no_grad():
         preds = model(x)
     det = getattr(model, "_detector", None)
@@ -142,7 +166,7 @@ def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_
     for im in images:
         pil = im if isinstance(im, Image.Image) else Image.open(im)
         pil, scale, pad_top, pad_left = letterbox_resize(pil.convert("RGB"), S)
-        xs.append(torch.from_numpy(np.array(pil)).permute(2, 0, 1).float() / 255.0)
+        xs.append(torch.from_numpy(np.array(pil)))                   # (S,S,3) uint8; /255 on the device (true division)
         meta.append((pad_left, pad_top, scale))
     if not xs:
         return []
@@ -162,10 +186,19 @@ def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_
 
 
 class InferenceSession:
-    """bs=1 end-to-end inference (BASELINE config 5): NCHW->NHWC, BN-folded fused convs, candidate
-    extraction and global NMS, captured ONCE into a hipGraph (via torch.cuda.CUDAGraph on the launch
-    stream) and replayed per image.  Everything the graph touches has a fixed address: the input image,
-    the letterbox parameters {pad_left, pad_top, scale} and all outputs live in static device buffers."""
+    """bs=1 end-to-end inference (BASELINE config 5): image load (NCHW float -> NHWC, or HWC uint8 -> NHWC with the
+    reference's /255), BN-folded fused convs, candidate extraction, global NMS, the result table and its device->host
+    copy, captured ONCE into a hipGraph (via torch.cuda.CUDAGraph on the launch stream) and replayed per image.
+    Everything the graph touches has a fixed address: the input image, the letterbox parameters {pad_left, pad_top,
+    scale}, all outputs and the pinned host mirror of the result table.
+
+    Per image the host does: one cheap weight-state check, one host->device copy of the image, one graph launch, one
+    stream synchronisation, and reads the kept rows out of pinned memory.
+
+    Weight changes: anything done through this package (optimizer steps, training forwards, load_state_dict, .to()) or
+    through in-place torch ops on the registered parameters / buffers is picked up automatically.  After writes torch cannot
+    see on those tensors (`p.data.mul_()`, `trainer.flat_p` views, in-place collectives) call
+    `model.invalidate_folded_weights()`; after re-assigning a parameter / buffer attribute call `session.refresh()`."""
 
     def __init__(self, model, conf_threshold=0.5, iou_threshold=0.4, use_graph=True, nms_mode=DEFAULT_NMS_MODE):
         self.model = model.eval()
@@ -176,15 +209,17 @@ class InferenceSession:
         self.conf, self.iou, self.nms_mode = float(conf_threshold), float(iou_threshold), nms_mode
         _nms_mode(nms_mode)
         self.x = torch.zeros(1, 3, self.S, self.S, device=self.device)
+        self.x_u8 = torch.zeros(1, self.S, self.S, 3, device=self.device, dtype=torch.uint8)
         self.lb = torch.tensor([0.0, 0.0, 1.0], device=self.device)
+        self._lb_host = (0.0, 0.0, 1.0)
         self.use_graph = bool(use_graph)
         self.det = None
         self._build()
 
     def _build(self):
-        """Trace the eval plan and (re)capture the hipGraph.  Called again by run() when a parameter, BatchNorm
+        """Trace the eval plan; hipGraphs are (re)captured lazily per input kind.  Called again when a parameter, BatchNorm
         buffer or the model's mode moved under the plan (HipTrainer adopting the parameters, load_state_dict(assign=True),
-        ...): the op lists and the captured graph hold raw device addresses."""
+        ...): the op lists and the captured graphs hold raw device addresses."""
         model = self.model.eval()
         with torch.no_grad():
             self.plan = model._plan_for(self.x)
@@ -192,41 +227,75 @@ class InferenceSession:
         grids = [v.H for v in self.heads]
         if self.det is None or self.det.grids != grids:
             self.det = Detector(grids, self.nc, self.device)
-        self.graph = None
+        self.graphs = {}
         self.plan.refresh_folded_weights(_stream(self.device))
-        if self.use_graph:
-            side = torch.cuda.Stream(self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self._enqueue()            # warm-up: kernel attributes, lazy module state
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._enqueue()
+        self._fold_inputs = self.plan.fold_inputs()
+        self._vsum = sum(t._version for t in self._fold_inputs)
+        self._token = state_token()
 
-    def _enqueue(self):
+    def refresh(self):
+        """Full re-validation: re-trace if any tensor moved, re-fold if any value may have changed."""
+        if self.plan.params_moved():
+            self._build()
+            return
+        self._fold_inputs = self.plan.fold_inputs()
+        self._vsum = sum(t._version for t in self._fold_inputs)
+        self._token = state_token()
+        self.plan.refresh_folded_weights(_stream(self.device))
+
+    def _check_state(self):
+        """Per image: one tuple compare + the version counters of the cached fold inputs (no module-tree walk)."""
+        if state_token() != self._token:
+            self.refresh()
+            return
+        v = 0
+        for t in self._fold_inputs:
+            v += t._version
+        if v != self._vsum:
+            self._vsum = v
+            self.plan.refresh_folded_weights(_stream(self.device))
+
+    def _capture(self, kind: str):
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._enqueue(kind)            # warm-up: kernel attributes, lazy module state
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(kind)
+        self.graphs[kind] = g
+        return g
+
+    def _enqueue(self, kind: str):
         """Everything a replay repeats.  BatchNorm folding is NOT in here: it depends on the weights only and runs (eagerly,
-        before the replay) when Plan.refresh_folded_weights sees a new weight state."""
-        self.model._load_input(self.plan, self.x)
+        before the replay) when the weight state changed."""
+        self.model._load_input(self.plan, self.x if kind == "f32" else self.x_u8)
         L.run_ops(self.plan.fwd_ops[0], self.plan.fwd_ops[1], _stream(self.device), self.plan._ctx())
         preds = [v.buf.data.view(1, v.H, v.W, 3, v.C // 3) for v in self.heads]
         self.det.candidates(preds, self.model.anchors, self.S, self.conf, letterbox_dev=self.lb)
         self.det.nms(self.iou, self.nms_mode)
+        self.det.gather()
 
     def run(self, img: torch.Tensor, pad_left=0.0, pad_top=0.0, scale=1.0, fetch=True):
-        """img: (1,3,S,S) or (3,S,S) float tensor (host or device).  Returns the detections list."""
-        if self.plan.params_moved():
-            self._build()
-        self.plan.refresh_folded_weights(_stream(self.device))
-        self.x.copy_(img.reshape(self.x.shape), non_blocking=True)
-        self.lb.copy_(torch.tensor([pad_left, pad_top, scale], dtype=torch.float32), non_blocking=True)
-        if self.graph is not None:
-            self.graph.replay()
+        """img: (1,3,S,S) / (3,S,S) float32 in [0,1], or (S,S,3) / (1,S,S,3) uint8 image bytes (divided by 255 on the
+        device exactly like train.py:1137), host or device; pinned host tensors copy asynchronously.  Returns the
+        detections list [(x1,y1,x2,y2,conf,class_id)] (fetch=False: enqueue only, `session.det.read()` later)."""
+        self._check_state()
+        kind = "u8" if img.dtype == torch.uint8 else "f32"
+        dst = self.x_u8 if kind == "u8" else self.x
+        dst.copy_(img.reshape(dst.shape), non_blocking=True)
+        lb = (float(pad_left), float(pad_top), float(scale))
+        if lb != self._lb_host:
+            self.lb.copy_(torch.tensor(lb, dtype=torch.float32))
+            self._lb_host = lb
+        if self.use_graph:
+            (self.graphs.get(kind) or self._capture(kind)).replay()
         else:
-            self._enqueue()
-        return self.det.fetch() if fetch else None
+            self._enqueue(kind)
+        return self.det.read() if fetch else None
 
 
 def assign_targets_gpu(labels, img_size, num_classes, device, anchors=None):

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .graph import Plan, View
+from .graph import Plan, View, PARAM_GENERATION, invalidate_folded_weights
 
 DEFAULT_ANCHORS = [[[10, 13], [16, 30], [33, 23]], [[30, 61], [62, 45], [59, 119]],
                    [[116, 90], [156, 198], [373, 326]]]          # train.py:372-374
@@ -79,6 +79,26 @@ class HipModule(nn.Module):
             raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {dtype!r}")
         self._compute_dtype = dtype
         return self
+
+    # -- weight-state bookkeeping (plans and captured hipGraphs hold raw addresses and folded copies) ---
+    def invalidate_folded_weights(self):
+        """Call after writing parameter / BatchNorm-buffer storage in a way torch's version counters of the registered
+        tensors do not see (`p.data.mul_()`, writes through `trainer.flat_p`, in-place collectives): eval plans and
+        InferenceSessions then re-fold BatchNorm before their next forward.  See graph.invalidate_folded_weights."""
+        invalidate_folded_weights()
+        return self
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)        # .to() / .cuda() / .float(): storage may have moved
+        PARAM_GENERATION[0] += 1
+        invalidate_folded_weights()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        PARAM_GENERATION[0] += 1                 # assign=True replaces the tensors; values changed either way
+        invalidate_folded_weights()
+        return out
 
     # -- to be provided by subclasses ------------------------------------------------------------
     def _emit(self, g: Plan, x: View, out: Optional[View] = None) -> View:

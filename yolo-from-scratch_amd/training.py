@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from .functional import LOSS_IMG_SIZE, _anchors18, run_loss_kernel, yolo_loss_multiscale
-from .graph import WEIGHTS_EPOCH
+from .graph import WEIGHTS_EPOCH, PARAM_GENERATION, invalidate_folded_weights
 from .hostside import stack_targets
 from .modules import HipModule
 
@@ -117,6 +117,7 @@ class HipTrainer:
                 p.grad = views[id(p)]                     # and their .grad in the flat gradient buffer
                 self.offsets[id(p)] = (off, p.numel())
                 off += (p.numel() + 3) // 4 * 4
+        PARAM_GENERATION[0] += 1                          # every parameter moved: plans re-trace, hipGraphs re-capture
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.norm = torch.zeros(1, device=self.device, dtype=torch.float32)
@@ -130,6 +131,16 @@ class HipTrainer:
         if self.world > 1:
             dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                            group=process_group)      # identical replicas
+            invalidate_folded_weights()              # written through the flat view: torch's version counters of the parameters did not move
+
+    @torch.no_grad()
+    def load_flat_parameters(self, flat: torch.Tensor):
+        """Overwrite all parameters from a flat fp32 vector laid out like `flat_p` (resume, EMA swap, parameter server):
+        the one sanctioned way to write through the flat buffer -- it also invalidates folded inference weights."""
+        if flat.numel() != self.flat_p.numel():
+            raise ValueError(f"expected {self.flat_p.numel()} values, got {flat.numel()}")
+        self.flat_p.copy_(flat.reshape(-1).to(self.flat_p))
+        invalidate_folded_weights()
 
     def _plan_segments(self, plan):
         spans = [(self.offsets[id(p)][0], (self.offsets[id(p)][1] + 3) // 4 * 4) for p in self._params]
