@@ -117,13 +117,16 @@ def host_cores():
     return n
 
 
-def stored_traffic():
+PROFILE_ROUND = "r03"
+
+
+def stored_traffic(nc, img, batch, dtype, size):
     """HBM bytes of the forward-convolution launches from the committed rocprofv3 PMC profile -- quoted only when the profile
     was taken on exactly these kernels (tools/provenance.py: hash of csrc/ + the C header); otherwise null."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from provenance import csrc_hash
-    path = os.path.join(ROOT, "profiles", f"r02_step_profile_{DTYPE}.json")
-    if not os.path.exists(path) or (NC, IMG, BATCH, SIZE) != ((1, 640, 64, "s") if DTYPE == "f32" else (80, 640, 64, "s")):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_step_profile_{dtype}.json")
+    if not os.path.exists(path) or (nc, img, batch, size) != ((1, 640, 64, "s") if dtype == "f32" else (80, 640, 64, "s")):
         return None, f"no committed PMC profile for this workload ({os.path.basename(path)})"
     doc = json.load(open(path))
     if doc.get("stamp", {}).get("csrc_sha16") != csrc_hash():
@@ -175,6 +178,149 @@ def self_launch(args):
     raise SystemExit(proc.returncode)
 
 
+FORCE_COLLECTIVES = [False]     # --collectives-at-world-1: rehearse the RCCL leg with ONE rank (tests/test_gpu_dp.py)
+
+
+def timed_training(y, dist, dev, rank, world, nc, img, batch, dtype, size, steps, warmup):
+    """W untimed + exactly K timed steps bracketed by barrier + synchronize, max over ranks.  Returns the line's base fields
+    plus the live objects the roofline instrumentation needs."""
+    torch.manual_seed(0)                                   # identical replicas
+    model = y.YOLO(num_classes=nc, img_size=img, width_mult=y.YOLO_SIZES[size][0], depth_mult=y.YOLO_SIZES[size][1]).to(dev)
+    trainer = y.HipTrainer(model, lr=1e-3, max_norm=10.0, dtype=dtype, collectives_at_world_1=FORCE_COLLECTIVES[0])
+    imgs = torch.rand(batch, 3, img, img, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    targets = [t.to(dev) for t in y.synthetic_targets(batch, nc, img, 8, 2000 + rank)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        trainer.step(imgs, targets)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(imgs, targets)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    base = {"value": round(batch * world * steps / elapsed, 2), "unit": "images/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "steps": steps, "warmup": warmup, "loss": [round(v, 6) for v in trainer.loss_out[:4].tolist()]}
+    return base, model, trainer, imgs, targets
+
+
+def roofline_bf16(model, trainer, imgs, targets, nc, img, batch, size):
+    """bf16: every layer of size 's' is HBM-bound, so the roofline is bytes: algorithmic activation bytes of the
+    forward convolutions (each input view read once, each output written once) / HIP-event time of those launches."""
+    from yolo_from_scratch_amd import _lib as L
+    plan = model._plan_for(imgs)
+    conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
+    nbytes = plan_conv_bytes(plan) * batch
+    flops = plan_conv_flops(plan)[0] * batch
+    ach = nbytes / (conv_ms * 1e-3) / 1e9
+    bn_ms = per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BF16_BN_SILU_FWD, 0.0)
+    traffic, note = stored_traffic(nc, img, batch, "bf16", size)
+    roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_note": note,
+            "kernel": "forward convolutions: bf16_gemm_kernel (gather implicit GEMM on v_mfma_f32_32x32x16_bf16)",
+            "kernel_ms_per_step": round(conv_ms, 3), "launches_per_step": n_launch,
+            "algorithmic_gbytes_per_step": round(nbytes / 1e9, 3),
+            "algorithmic_gflop_per_step": round(flops / 1e9, 2),
+            "conv_tflops": round(flops / (conv_ms * 1e-3) / 1e12, 1),
+            "conv_bn_silu_forward_ms_per_step": round(conv_ms + bn_ms, 3),
+            "whole_forward_ms_serial": round(per_kind["whole_forward_serial"], 3),
+            "whole_forward_ms_with_lanes": round(per_kind["whole_forward_lanes"], 3)}
+    return roof, {str(k): round(v, 3) for k, v in sorted(per_kind.items(), key=lambda kv: str(kv[0]))}
+
+
+def roofline_f32(model, trainer, imgs, targets, nc, img, batch, size):
+    from yolo_from_scratch_amd import _lib as L
+    plan = model._plan_for(imgs)
+    conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
+    flops, flops_wino = (v * batch for v in plan_conv_flops(plan))
+    ach = flops / (conv_ms * 1e-3) / 1e12
+    # the Winograd kernel executes 4/9 of the direct form's multiplies: the rate the MFMA pipe actually runs at
+    executed = flops - flops_wino * (1.0 - 4.0 / 9.0)
+    traffic, traffic_note = stored_traffic(nc, img, batch, "f32", size)
+    cbs_ms = conv_ms + per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BN_SILU_FWD, 0.0)
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": traffic_note + "; algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
+            "executed_mfma_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 2),
+            "executed_mfma_frac": round(executed / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernel": "forward convolutions: wino_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
+                      "the algorithmic multiplies) + pw_tile_kernel / pw_stream_kernel (1x1) + gather_gemm_kernel (stride-2, "
+                      "head outputs) + narrow_conv_kernel (16-channel 3x3 layers, stem[3], stem[0])",
+            "narrow_ms_per_step": round(per_kind.get(L.OP_CONV_NARROW, 0.0), 3),
+            "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
+            "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
+            "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0) + per_kind.get(L.OP_CONV_PW_FWD2, 0.0), 3),
+            "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
+            "launches_per_step": n_launch,
+            # north_star's target quantity: the whole Conv+BN+SiLU forward against the same peak.  Two measurements:
+            # (a) sum of the per-op event times of conv + statistics finalize + normalise/SiLU ops (each op bracketed by
+            # its own event pair, which adds a few us per op); (b) the entire forward op list timed as one call, serial
+            # (everything: also weight packs, pools, head convs) -- no per-op events
+            "conv_bn_silu_forward_ms_per_step": round(cbs_ms, 3),
+            "conv_bn_silu_forward_frac": round(flops / (cbs_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "whole_forward_ms_serial": round(per_kind["whole_forward_serial"], 3),
+            "whole_forward_ms_with_lanes": round(per_kind["whole_forward_lanes"], 3),
+            "whole_forward_frac_serial": round(flops / (per_kind["whole_forward_serial"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "whole_forward_frac_with_lanes": round(flops / (per_kind["whole_forward_lanes"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
+    return roof, {str(k): round(v, 3) for k, v in sorted(per_kind.items(), key=lambda kv: str(kv[0]))}
+
+
+def detecting_model(y, nc, img=640):
+    """BASELINE config 5's model: untrained weights give no detections, so the objectness is spread (prior 0.2, head weights
+    x60), the BatchNorm running statistics are warmed, and the confidence threshold is set for ~3000 candidates into NMS."""
+    torch.manual_seed(0)
+    m = y.YOLO(num_classes=nc, img_size=img)
+    m.initialize_detection_biases(prior=0.2)
+    with torch.no_grad():
+        for hd in (m.head_p3, m.head_p4, m.head_p5):
+            hd[-1].weight.mul_(60.0)
+    m = m.cuda().train()
+    with torch.no_grad():
+        for _ in range(3):
+            m(torch.rand(4, 3, img, img, device="cuda"))
+    m.eval()
+    probe = torch.rand(1, 3, img, img, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        obj = torch.cat([torch.sigmoid(p[..., 4]).flatten() for p in m(probe.cuda())])
+    return m, float(torch.sort(obj, descending=True).values[3000])
+
+
+def infer_latency(y, nc=1, iters=100):
+    """BASELINE config 5: bs=1 640x640, H2D image copy (pinned fp32 NCHW, 4.9 MB), NCHW->NHWC, BN-folded fused forward,
+    candidates, global NMS, result table, D2H, python list -- eager launches vs ONE captured hipGraph."""
+    m, thr = detecting_model(y, nc)
+    img = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(7)).pin_memory()
+    out = {"workload": f"nc={nc} 640x640 bs=1 eval, BN folded, ~3000 candidates into NMS, pinned fp32 NCHW host image in, "
+                       "python list of (x1,y1,x2,y2,conf,cls) out", "unit": "ms", "iters": iters}
+    for name, use_graph in (("eager", False), ("hipgraph", True)):
+        ses = y.InferenceSession(m, conf_threshold=thr, iou_threshold=0.4, use_graph=use_graph)
+        for _ in range(10):
+            dets = ses.run(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dets = ses.run(img)                        # includes the D2H fetch (host sync) like predict()
+        dt = (time.perf_counter() - t0) / iters
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ses.run(img, fetch=False)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = {"end_to_end_ms": round(dt * 1e3, 3), "device_ms": round(e0.elapsed_time(e1) / iters, 3),
+                     "candidates": int(ses.det.count.item()), "kept": len(dets)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,9 +328,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16 nc=80 (config 3) and bs=1 inference (config 5) legs")
+    ap.add_argument("--collectives-at-world-1", action="store_true",
+                    help="with ONE rank under torch.distributed.run: still broadcast and all-reduce the gradient buckets over RCCL")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
+    FORCE_COLLECTIVES[0] = bool(args.collectives_at_world_1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)          # before anything touches the GPU in this process
 
@@ -193,7 +343,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    use_pg = args.gpus > 1 or "WORLD_SIZE" in os.environ        # under torch.distributed.run even ONE rank goes through RCCL
+    if use_pg:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -210,101 +361,48 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    torch.manual_seed(0)                                   # identical replicas
-    model = y.YOLO(num_classes=NC, img_size=IMG, width_mult=y.YOLO_SIZES[SIZE][0], depth_mult=y.YOLO_SIZES[SIZE][1]).to(dev)
-    trainer = y.HipTrainer(model, lr=1e-3, max_norm=10.0, dtype=DTYPE)
-    imgs = torch.rand(BATCH, 3, IMG, IMG, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
-    targets = [t.to(dev) for t in y.synthetic_targets(BATCH, NC, IMG, 8, 2000 + rank)]
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        trainer.step(imgs, targets)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(imgs, targets)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    loss = trainer.loss_out[:4].tolist()
-
+    headline = (NC, IMG, BATCH, DTYPE, SIZE) == (1, 640, 64, "f32", "s")
+    base, model, trainer, imgs, targets = timed_training(y, dist, dev, rank, world, NC, IMG, BATCH, DTYPE, SIZE, args.steps, args.warmup)
     result = {
-        "metric": "images/sec training step, 640x640 bs=64/GPU" if (NC, IMG, BATCH, DTYPE, SIZE) == (1, 640, 64, "f32", "s") else
-                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} {DTYPE} size {SIZE} (informational shape)", "value": round(BATCH * world * args.steps / elapsed, 2),
-        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "metric": "images/sec training step, 640x640 bs=64/GPU" if headline else
+                  f"images/sec training step, {IMG}x{IMG} bs={BATCH}/GPU nc={NC} {DTYPE} size {SIZE} (informational shape)",
+        "value": base["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": base["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"nc={NC} {IMG}x{IMG} bs={BATCH}/GPU full training step (fwd+loss+bwd+clip10+Adam), model size {SIZE}, "
                                + ("fp32 MFMA" if DTYPE == "f32" else "bf16 MFMA convolutions, bf16 activations, fp32 master weights / statistics / loss"),
                    "global_batch": BATCH * world, "parallelism": f"dp{world}"},
-        "loss": [round(v, 6) for v in loss],
+        "loss": base["loss"],
     }
-    if rank == 0 and not args.no_roofline and DTYPE == "bf16":
-        # bf16: every layer of this network is HBM-bound, so the roofline is bytes: algorithmic activation bytes of
-        # the forward convolutions (each input view read once, each output written once) / HIP-event time of those launches
-        plan = model._plan_for(imgs)
-        from yolo_from_scratch_amd import _lib as L
-        conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
-        nbytes = plan_conv_bytes(plan) * BATCH
-        flops = plan_conv_flops(plan)[0] * BATCH
-        ach = nbytes / (conv_ms * 1e-3) / 1e9
-        bn_ms = per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BF16_BN_SILU_FWD, 0.0)
-        result["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": stored_traffic()[0], "traffic_note": stored_traffic()[1],
-                              "kernel": "forward convolutions: bf16_gemm_kernel (gather implicit GEMM on v_mfma_f32_32x32x16_bf16)",
-                              "kernel_ms_per_step": round(conv_ms, 3), "launches_per_step": n_launch,
-                              "algorithmic_gbytes_per_step": round(nbytes / 1e9, 3),
-                              "algorithmic_gflop_per_step": round(flops / 1e9, 2),
-                              "conv_tflops": round(flops / (conv_ms * 1e-3) / 1e12, 1),
-                              "conv_bn_silu_forward_ms_per_step": round(conv_ms + bn_ms, 3),
-                              "whole_forward_ms_serial": round(per_kind["whole_forward_serial"], 3),
-                              "whole_forward_ms_with_lanes": round(per_kind["whole_forward_lanes"], 3)}
-        result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items(), key=lambda kv: str(kv[0]))}
-    if rank == 0 and not args.no_roofline and DTYPE == "f32":
-        plan = model._plan_for(imgs)
-        from yolo_from_scratch_amd import _lib as L
-        conv_ms, n_launch, per_kind = time_forward_convs(trainer, plan, imgs, targets, 3)
-        flops, flops_wino = (v * BATCH for v in plan_conv_flops(plan))
-        ach = flops / (conv_ms * 1e-3) / 1e12
-        traffic, traffic_note = stored_traffic()
-        result["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                              "traffic_note": traffic_note + "; algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
-                              "kernel": "forward convolutions: wino_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
-                                        "the algorithmic multiplies) + pw_tile_kernel / pw_stream_kernel (1x1) + gather_gemm_kernel (stride-2, "
-                                        "head outputs) + narrow_conv_kernel (16-channel 3x3 layers, stem[3], stem[0])",
-                              "narrow_ms_per_step": round(per_kind.get(L.OP_CONV_NARROW, 0.0), 3),
-                              "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
-                              "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
-                              "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0) + per_kind.get(L.OP_CONV_PW_FWD2, 0.0), 3),
-                              "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
-                              "launches_per_step": n_launch,
-                              # north_star's target quantity: the whole Conv+BN+SiLU forward against the same peak.  Two
-                              # measurements: (a) sum of the per-op event times of conv + statistics finalize + normalise/
-                              # SiLU ops (each op bracketed by its own event pair, which adds a few us per op);
-                              # (b) the entire forward op list timed as one call, serial (everything: also weight packs,
-                              # pools, head convs) -- no per-op events
-                              "conv_bn_silu_forward_ms_per_step": round(conv_ms + per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BN_SILU_FWD, 0.0), 3),
-                              "conv_bn_silu_forward_frac": round(flops / ((conv_ms + per_kind.get(L.OP_BN_FINALIZE, 0.0) + per_kind.get(L.OP_BN_SILU_FWD, 0.0)) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              "whole_forward_ms_serial": round(per_kind["whole_forward_serial"], 3),
-                              "whole_forward_ms_with_lanes": round(per_kind["whole_forward_lanes"], 3),
-                              "whole_forward_frac_serial": round(flops / (per_kind["whole_forward_serial"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              "whole_forward_frac_with_lanes": round(flops / (per_kind["whole_forward_lanes"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                              "kernel_ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 2)}
-        result["forward_ms_by_op"] = {str(k): round(v, 3) for k, v in sorted(per_kind.items(), key=lambda kv: str(kv[0]))}
+    if rank == 0 and not args.no_roofline:
+        roof, by_op = (roofline_bf16 if DTYPE == "bf16" else roofline_f32)(model, trainer, imgs, targets, NC, IMG, BATCH, SIZE)
+        result["roofline"], result["forward_ms_by_op"] = roof, by_op
+    if world > 1:
+        dist.barrier()
+    del trainer, model, imgs, targets
+    torch.cuda.empty_cache()
+
+    # ---- extra keys of the same line (headline run only): BASELINE config 3's per-GPU workload in bf16, config 5's latency
+    if headline and not args.no_extras:
+        b, model, trainer, imgs, targets = timed_training(y, dist, dev, rank, world, 80, 640, 64, "bf16", "s", 25, 5)
+        extra = {"workload": "nc=80 640x640 bs=64/GPU full training step, bf16 MFMA convolutions + bf16 activations, fp32 master "
+                             "weights / statistics / loss (BASELINE config 3 per GPU)", "dtype": "bf16", "n_gpus": world, **b}
+        if rank == 0 and not args.no_roofline:
+            extra["roofline"], extra["forward_ms_by_op"] = roofline_bf16(model, trainer, imgs, targets, 80, 640, 64, "s")
+        result["bf16_nc80"] = extra
+        if world > 1:
+            dist.barrier()
+        del trainer, model, imgs, targets
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
+            result["infer"] = infer_latency(y, 1)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         if (IMG, SIZE) == (640, "s"):       # BASELINE configs[0]: the reference's own CPU-runnable case, batch 2
             b2 = cpu_baseline(batch=2, steps=5)
             result["cpu_baseline"]["config1_batch2"] = {"value": b2["value"], "unit": b2["unit"], "sample": b2["sample"]}
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

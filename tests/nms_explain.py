@@ -98,7 +98,7 @@ def explain_detections(det, hip_preds, ref_preds, anchors, img_size, nc, conf_th
     assert int(in_hip.sum()) == M
     differ = in_ref != in_hip
     assert bool(((obj_ref[differ] - conf_thr).abs() <= delta / 4 + 1e-7).all())                    # (b)
-    assert int(differ.sum()) <= max(2, M // 100)
+    assert int(differ.sum()) <= max(2, M // 20), (int(differ.sum()), M, delta)      # sanity: the band of (b) is narrow
     ab, asx, ac = orc.candidates(ref_preds, anchors, img_size, nc, -1.0, *letterbox)             # every cell, candidate order
     cells = torch.nonzero(in_hip).reshape(-1)
     same_cls = ac[cells].numpy() == gc

@@ -105,3 +105,36 @@ def test_two_rank_trainer_matches_oracle_on_shards(tmp_path):
             assert float((d_got - d_ref).abs().max()) <= 3e-2 * float(d_ref.abs().max()), n
             checked += int(strong.sum())
     assert checked > 1000
+
+
+def test_rccl_leg_runs_on_one_rank_and_is_the_identity(tmp_path):
+    """The RCCL leg of the data-parallel step (train.py:905-918 is the body being sharded) on the hardware available to the
+    tests: ONE rank over torch's "nccl" backend (= RCCL), with the bucketed collectives forced on.  An all-reduce over one rank
+    is the identity, so three steps must be BITWISE equal to the non-distributed trainer -- any ordering bug between RCCL's
+    stream, the side lane of yh_run and the optimizer kernels shows up as a difference."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "tests" / "rccl_gpu_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = torch.load(tmp_path / "rccl1.pt", weights_only=True)
+    assert res["backend"] == "nccl" and res["world"] == 1
+    for dtype in ("f32", "bf16"):
+        d, p = res[dtype]["dist"], res[dtype]["plain"]
+        assert d["active"] and d["n_reduces"] >= 3 and not p["active"] and p["n_reduces"] == 0
+        assert torch.equal(d["losses"], p["losses"]) and torch.equal(d["g"], p["g"]) and torch.equal(d["p"], p["p"]), dtype
+        assert bool(torch.isfinite(d["losses"]).all())
+
+
+def test_bench_runs_under_torch_distributed_run_with_one_rank(tmp_path):
+    """bench.py's multi-GPU branch (init_process_group("nccl", device_id=...), barrier, max over ranks, destroy) executed the way
+    the driver launches it, at the one world size a one-GPU box allows."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", YH_BENCH_SHAPE="1,320,4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-roofline", "--no-extras", "--collectives-at-world-1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1"

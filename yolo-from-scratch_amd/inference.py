@@ -98,9 +98,9 @@ class Detector:
             rows = self._out_np[8: 8 + 6 * k].copy()
         else:
             rows = self.out[8: 8 + 6 * k].cpu().numpy()
-        rows = rows.reshape(k, 6)
-        cls = rows[:, 5].copy().view(np.int32).tolist()
-        return [(r[0], r[1], r[2], r[3], r[4], c) for r, c in zip(rows.tolist(), cls)]
+        cols = np.ascontiguousarray(rows.reshape(k, 6).T)          # six contiguous columns -> python lists -> zip (all in C)
+        return list(zip(cols[0].tolist(), cols[1].tolist(), cols[2].tolist(), cols[3].tolist(), cols[4].tolist(),
+                        cols[5].view(np.int32).tolist()))
 
     def fetch(self) -> List[Tuple[float, float, float, float, float, int]]:
         self.gather()

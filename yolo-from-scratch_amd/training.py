@@ -50,15 +50,20 @@ class GradBuckets:
     (SUM; the 1/world factor is folded into the clip+Adam kernel) can be issued while the rest of the
     backward still runs.  `plan_segments` returns [(n_ops_done, (begin, end) | None), ...]."""
 
-    def __init__(self, flat_g: torch.Tensor, process_group=None, n_buckets: int = 4):
+    def __init__(self, flat_g: torch.Tensor, process_group=None, n_buckets: int = 4, collectives_at_world_1: bool = False):
+        """collectives_at_world_1: issue the bucketed collectives even when the group has ONE rank (an all-reduce over one
+        rank is the identity, so the step must stay bitwise equal to the non-distributed one): the whole RCCL leg -- lazy
+        communicator creation, side-stream ordering against the backward segments, wait -- can then be exercised on a
+        one-GPU box (tests/test_gpu_dp.py)."""
         self.flat_g, self.pg, self.n_buckets = flat_g, process_group, max(1, n_buckets)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(collectives_at_world_1) and dist.is_initialized())
         self._works = []
 
     def plan_segments(self, spans, ready, n_ops):
         """spans: [(offset, padded_numel)] per parameter in registration order; ready: op count after
         which each parameter's gradient is final; n_ops: length of the backward op list."""
-        if self.world == 1:
+        if not self.active:
             return [(n_ops, None)]
         total = self.flat_g.numel()
         target = total / self.n_buckets
@@ -77,7 +82,7 @@ class GradBuckets:
         return buckets
 
     def launch(self, rng):
-        if self.world > 1 and rng is not None:
+        if self.active and rng is not None:
             self._works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.pg,
                                                async_op=True))
 
@@ -91,8 +96,9 @@ class HipTrainer:
     """Owns the flat parameter / gradient / Adam-state buffers of a YOLO model and runs fused steps."""
 
     def __init__(self, model: HipModule, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = 10.0,
-                 process_group=None, n_buckets: int = 4, dtype: Optional[str] = None):
-        """dtype: None keeps the model's compute dtype; 'bf16' / 'f32' set it (HipModule.set_compute_dtype)."""
+                 process_group=None, n_buckets: int = 4, dtype: Optional[str] = None, collectives_at_world_1: bool = False):
+        """dtype: None keeps the model's compute dtype; 'bf16' / 'f32' set it (HipModule.set_compute_dtype).
+        collectives_at_world_1: see GradBuckets (test hook: run broadcast + bucketed all-reduces on a 1-rank group)."""
         self.model = model
         if dtype is not None:
             model.set_compute_dtype(dtype)
@@ -124,11 +130,11 @@ class HipTrainer:
         self.norm_ws = torch.empty(int(L.lib().yh_sqnorm_ws(n)) + 2, device=self.device, dtype=torch.float64)
         self.loss_out = torch.zeros(13, device=self.device, dtype=torch.float32)
         self._loss_ws = None
-        self.buckets = GradBuckets(self.flat_g, process_group, n_buckets)
+        self.buckets = GradBuckets(self.flat_g, process_group, n_buckets, collectives_at_world_1)
         self.pg, self.world = process_group, self.buckets.world
         self._segments = None
         self._params = params
-        if self.world > 1:
+        if self.buckets.active:
             dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                            group=process_group)      # identical replicas
             invalidate_folded_weights()              # written through the flat view: torch's version counters of the parameters did not move
