@@ -31,20 +31,51 @@ def _detecting_model(y, nc, S, seed, gain, prior=0.3):
     return m
 
 
+def _calibrated_model(y, nc, S, seed, gain=6.0, prior=0.05, warm=24):
+    """A random-weight model whose outputs DEPEND on the image: with the default running statistics (mean 0, var 1) the
+    signal of a freshly initialised net dies out layer by layer and every cell sees the head bias.  The BatchNorm running
+    statistics are therefore calibrated with `warm` training-mode forwards of the CPU oracle on random images."""
+    torch.manual_seed(seed)
+    m = y.YOLO(num_classes=nc, img_size=S)
+    m.initialize_detection_biases(prior=prior)
+    with torch.no_grad():
+        for hd in (m.head_p3, m.head_p4, m.head_p5):
+            hd[-1].weight.mul_(gain)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        for k in range(warm):
+            orc.forward(P, torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(100 + k)), nc, training=True)
+    m.load_state_dict(P)
+    return m, P
+
+
 @pytest.mark.parametrize("nc", [1, 80])
 def test_config5_640_hipgraph_matches_eager_and_oracle(nc):
     from nms_explain import explain_detections
     y = api()
     S = 640
-    m = _detecting_model(y, nc, S, 11 + nc, 30.0)
-    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m, P = _calibrated_model(y, nc, S, 11 + nc)
     m = m.cuda().eval()
     rng = np.random.default_rng(5)
     probe = torch.from_numpy((rng.random((S, S, 3)) * 255).astype(np.uint8))
     with torch.no_grad():
         obj = torch.cat([torch.sigmoid(p[..., 4]).flatten() for p in m(probe.unsqueeze(0).cuda())]).sort(descending=True).values
+
+    def gap_threshold(k):
+        """A threshold between two DISTINCT objectness values with about k cells above it (random images through random
+        weights give large plateaus of identical logits; a threshold ON a plateau is decided by the last bit of the sigmoid)."""
+        vals, counts = torch.unique(obj, return_counts=True)           # ascending
+        above = counts.flip(0).cumsum(0).flip(0)                       # cells with obj >= vals[i]
+        ok = (above >= k // 2) & (above <= k + k // 2)
+        ok[0] = False
+        gaps = torch.where(ok, vals - vals.roll(1), torch.zeros_like(vals))
+        i = int(torch.argmax(gaps))
+        assert float(gaps[i]) > 1e-6, "no usable gap in the objectness distribution"      # >= 8 ulps of the sigmoid either side
+        return float((vals[i] + vals[i - 1]) / 2)
+
     # two thresholds: ~3000 candidates (torchvision's per-class branch) and ~600 (the coordinate trick, M <= 1000)
-    for conf, want_trick in ((float(obj[3000]), False), (float(obj[600]), True)):
+    for conf, want_trick in ((gap_threshold(3000), False), (gap_threshold(600), True)):
         eager = y.InferenceSession(m, conf_threshold=conf, iou_threshold=0.4, use_graph=False)
         graph = y.InferenceSession(m, conf_threshold=conf, iou_threshold=0.4, use_graph=True)
         for k in range(2):
