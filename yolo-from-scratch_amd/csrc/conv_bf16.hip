@@ -15,7 +15,7 @@
 //
 // MFMA operand maps (cdna guide section 3): v_mfma_f32_32x32x16_bf16, lane l (r = l & 31, h = l >> 5) holds
 // A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7; D register q of lane l = D[(q & 3) + 8 (q >> 2) + 4h][col r].
-#include "common.h"
+#include "bf16_common.h"
 #include <type_traits>
 #ifdef YH_BF_STAMPS
 #include <stdio.h>
@@ -26,11 +26,12 @@
 
 namespace {
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
+// YH_BF16_STREAM=0 (read once): route the stride-1 layers through the segment kernels of this file instead of the flat-stream
+// kernels of conv_bf16_stream.hip (A/B switch)
+bool use_stream() {
+    static const bool on = !(getenv("YH_BF16_STREAM") && atoi(getenv("YH_BF16_STREAM")) == 0);
+    return on;
+}
 
 constexpr int BK = 64;                 // k per chunk = 8 octets of 8 bf16 (16 bytes)
 constexpr int A_STRIDE = BK * 2 + 16;  // bytes per A-tile row: 144 -> the 16 rows of a ds_read_b128 lane group hit 16 distinct bank quads
@@ -61,11 +62,8 @@ struct BfGemmSet {
     BfGemm c[4];
 };
 
-__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
-    return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
-}
-
-__device__ __forceinline__ int mfma_row(int q, int lh) { return (q & 3) + 8 * (q >> 2) + 4 * lh; }
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) { return yh_fast_div(n, magic, shift); }
+__device__ __forceinline__ int mfma_row(int q, int lh) { return yh_mfma_row(q, lh); }
 
 // output pixel of GEMM row m (dense: the rows are the output pixels in order; otherwise a strided / offset sub-grid)
 __device__ __forceinline__ size_t out_pixel(const BfGemm &g, int m) {
@@ -447,12 +445,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
 #endif
 }
 
-void set_magic(unsigned d, unsigned &magic, int &shift) {
-    int l = 0;
-    while ((1u << l) < d) ++l;
-    magic = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
-    shift = l - 1;
-}
+void set_magic(unsigned d, unsigned &magic, int &shift) { yh_set_magic(d, magic, shift); }
 
 constexpr int GEMM_BM = 128;
 
@@ -930,6 +923,7 @@ extern "C" int yh_bf16_conv_bwd_data(const void *dy, int lddy, const void *dy2, 
 }
 
 extern "C" int64_t yh_bf16_conv_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
+    if (use_stream() && yh_bf16_wgrad_stream_ok(Wi, Cin, Cout, k, s)) return yh_bf16_wgrad_stream_ws(B, Hi, Wi, Cin, Cout, k);
     WgradPlan pl{};
     if (plan_wgrad(pl, B, Hi, Wi, Cin, Cout, k, s)) return -1;
     return (int64_t)pl.nsplit * k * k * Cin * Cout;
@@ -942,12 +936,23 @@ extern "C" int yh_bf16_conv_bwd_weight(const void *x, int ldx, const void *dy, i
     YH_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && ldx >= Cin && lddy >= ((Cout + 7) & ~7) &&
                    (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
                "bf16_conv_bwd_weight: channels / ld must be multiples of 8 (dY readable up to roundup8(Cout)) and views 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (use_stream() && yh_bf16_wgrad_stream_ok(Wi, Cin, Cout, k, s)) {
+        int nsplit = 0;
+        if (int rc = yh_bf16_wgrad_stream(x, ldx, dy, lddy, ws, ws_floats, B, Hi, Wi, Cin, Cout, k, &nsplit, st)) return rc;
+        const int total = k * k * Cin * Cout;
+        if (nsplit > 64)
+            hipLaunchKernelGGL(bf16_wgrad_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, st, ws, nsplit, k * k, Cin, cin_real, Cout, dw);
+        else
+            hipLaunchKernelGGL(bf16_wgrad_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, st, ws, nsplit, k * k, Cin, cin_real, Cout, dw);
+        YH_CHECK_LAUNCH("bf16_wgrad_reduce");
+        return 0;
+    }
     WgradPlan pl{};
     int rc = plan_wgrad(pl, B, Hi, Wi, Cin, Cout, k, s);
     if (rc) return rc;
     YH_REQUIRE(ws_floats >= (int64_t)pl.nsplit * k * k * Cin * Cout, "bf16_conv_bwd_weight: workspace too small");
     pl.g.x = (const bf16 *)x; pl.g.dy = (const bf16 *)dy; pl.g.ws = ws; pl.g.ldx = ldx; pl.g.lddy = lddy;
-    hipStream_t st = (hipStream_t)stream;
     if (k == 3) {
         if (pl.WI == 2 && pl.WJ == 2) rc = launch_wgrad_cfg<9, 2, 2>(pl, st);
         else if (pl.WI == 2) rc = launch_wgrad_cfg<9, 2, 1>(pl, st);

@@ -1,0 +1,355 @@
+// bf16 convolutions as FLAT PIXEL STREAMS (gfx950): the stride-1 layers (k = 1 and k = 3), which carry most of the bf16
+// path's bytes and are bound by HBM, not by the matrix pipe.
+//
+// The padded image batch is ONE 1-D sequence: position f = (b * VH + vy) * XW + vx with XW = W + 2 pad, VH = H + 2 pad
+// (pad = k / 2; padding positions hold zeros).  A 3x3 tap (kh, kw) is then a constant displacement (kh - 1) * XW + (kw - 1)
+// of that sequence -- no per-row segments, no per-segment halo reloads, no bounds arithmetic in the multiply loop:
+//
+//   dW[tap][ci][co] = sum_f  x[f + off(tap)][ci] * dy[f][co]          (dy = 0 at padding positions)
+//
+// A workgroup owns a (32 NI input channels) x (32 NJ output channels) x all-taps slab and a contiguous range of 64-position
+// blocks of the stream.  Both operands travel HBM -> registers -> LDS rings ONCE (the x ring keeps the 2 XW + 2 positions of
+// halo that the nine taps share); LDS images are planes of 32 channels with a 64-byte pixel stride, which makes the
+// transposing fragment reads (ds_read_b64_tr_b16: the reduction index -- pixels -- is the slow axis of NHWC) conflict-free
+// without padding.  Loads run PD = 3 blocks ahead in three register sets; one barrier per block; two workgroups per CU.
+//
+// Slabs are written in the layout of bf16_wgrad_reduce_kernel (conv_bf16.hip), whose fixed-order sum gives the OIHW fp32
+// gradient: bitwise reproducible.
+#include "bf16_common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct WgS {
+    const bf16 *x, *dy;
+    float *ws;
+    int ldx, lddy, Cin, Cout, cout8;
+    int H, W, XW, VH, pad, Mflat;
+    unsigned xw_magic, vh_magic;
+    int xw_shift, vh_shift;
+    int n_ci_tiles, ntiles, nsplit, nblk_total, blk_per_split;
+    int HB;          // halo of the nine taps in 64-position blocks: ceil((XW + 1) / 64), 0 for k = 1
+    int RX, RD;      // ring sizes in positions: (2 HB + 3) * 64 and 192
+    int tapoff[9];
+};
+
+// block = BP stream positions per pipeline step, PD = blocks requested ahead (PD - 1 register sets in flight).  What bounds a
+// workgroup's streaming rate is bytes in flight: (PD - 1) blocks against ~2 us of HBM latency.  3x3: BP 128, PD 4, one
+// 512-thread workgroup per CU (72 KB in flight); 1x1: BP 64, PD 3, up to three 256-thread workgroups per CU.
+// NT = threads per workgroup: the 3x3 form runs 8 waves on one set of rings (two waves per SIMD hide each other's LDS latency).
+template <int KK> struct WgsCfg { static constexpr int BP = KK == 9 ? 128 : 64, PD = KK == 9 ? 4 : 3, NT = KK == 9 ? 512 : 256, WPE = 2; };
+
+// flat position -> pixel index of the NHWC tensor; false for padding / out-of-range positions
+template <int KK>
+__device__ __forceinline__ bool wgs_pixel(const WgS &g, int f, int &pix) {
+    if (KK == 1) {
+        pix = f;
+        return (unsigned)f < (unsigned)g.Mflat;
+    }
+    const bool in = (unsigned)f < (unsigned)g.Mflat;
+    const int ff = in ? f : 0;
+    const int q1 = yh_fast_div(ff, g.xw_magic, g.xw_shift), vx = ff - q1 * g.XW - g.pad;
+    const int b = yh_fast_div(q1, g.vh_magic, g.vh_shift), vy = q1 - b * g.VH - g.pad;
+    pix = (b * g.H + vy) * g.W + vx;
+    return in && (unsigned)vx < (unsigned)g.W && (unsigned)vy < (unsigned)g.H;
+}
+
+__device__ __forceinline__ int wgs_mod(int v, int m) {        // v may be negative
+    int r = v % m;
+    return r < 0 ? r + m : r;
+}
+
+template <int KK, int NI, int NJ>
+__global__ __launch_bounds__(WgsCfg<KK>::NT, WgsCfg<KK>::WPE) void bf16_wgrad_stream_kernel(const WgS g) {
+    constexpr int BP = WgsCfg<KK>::BP, PD = WgsCfg<KK>::PD, NT = WgsCfg<KK>::NT;
+    constexpr int WK = (NT / 64) / (NI * NJ);    // wave groups that split the 16-position steps of a block
+    constexpr int PPT = NT / 4;                  // positions covered by one pass of the workgroup's threads
+    constexpr int NPIX = BP / PPT;               // positions per thread and block (thread t: positions (t >> 2) + PPT i)
+    static_assert(BP % PPT == 0 && (BP / 16) % WK == 0, "block shape");
+    constexpr int TG = KK == 9 ? 3 : 1;          // taps per round of the end-of-kernel wave reduction
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // provably wave-uniform: scalar branches, not EXEC masks
+    const int wi = wave_u % NI, wj = (wave_u / NI) % NJ, wk = wave_u / (NI * NJ);
+    const int RXp = g.RX + 16;                   // + mirror of the first 16 positions: a 16-position read never wraps
+    unsigned char *Xs = smem;                    // [NI][RXp][64 bytes]
+    unsigned char *Ds = smem + NI * RXp * 64;    // [NJ][RD][64 bytes]
+    // XCD-aware placement (workgroups b and b + 8 share an XCD and its L2): the ntiles workgroups that stream the SAME block
+    // range (different channel tiles) get consecutive slots of one XCD, so the second reader of a line finds it in L2.
+    // Bijective: whole groups of 8 splits are remapped, a trailing partial group keeps the plain order.
+    int split, tile;
+    {
+        const int lin = blockIdx.x, per = 8 * g.ntiles, full = (g.nsplit >> 3) * per;
+        if (lin < full) {
+            const int grp = lin / per, r = lin - grp * per, xcd = r & 7, w = r >> 3;
+            split = grp * 8 + xcd;
+            tile = w;
+        } else {
+            const int r = lin - full, rem = g.nsplit & 7;
+            split = (g.nsplit & ~7) + r % rem;
+            tile = r / rem;
+        }
+    }
+    const int ci0 = (tile % g.n_ci_tiles) * 32 * NI;
+    const int co0 = (tile / g.n_ci_tiles) * 32 * NJ;
+    const int j0 = split * g.blk_per_split;
+    int j1 = j0 + g.blk_per_split;
+    if (j1 > g.nblk_total) j1 = g.nblk_total;
+    const int nX = g.RX / BP, nD = g.RD / BP;
+
+    f32x16 acc[KK];
+#pragma unroll
+    for (int u = 0; u < KK; ++u)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+
+    // ---- staging: thread = (positions (t >> 2) + 64 i of the block, 16-byte chunk ch of a 32-channel plane) ---------------
+    const int pix = t >> 2, ch = t & 3;
+    const unsigned char *xb = (const unsigned char *)g.x, *db = (const unsigned char *)g.dy;
+    u32x4 rx[PD][NPIX * NI], rd[PD][NPIX * NJ];
+    unsigned mk[PD];                             // bits 0..: x pieces valid, bits 16..: dy pieces valid
+    // L(n): request x block n + HB + PD and dy block n + PD (stored PD - 1 iterations later).  Every load is issued
+    // unconditionally (a clamped address, zeroed when it is stored) so that the compiler's vmcnt bookkeeping stays exact.
+    auto issue = [&](int n, u32x4 (&ax)[NPIX * NI], u32x4 (&ad)[NPIX * NJ], unsigned &mko) __attribute__((always_inline)) {
+        unsigned m = 0;
+        const int bx = n + g.HB + PD, bd = n + PD;
+        const bool bxok = bx >= j0 - g.HB && bx < j1 + g.HB, bdok = bd >= j0 && bd < j1;
+#pragma unroll
+        for (int i = 0; i < NPIX; ++i) {
+            int px, pd;
+            const bool okx = wgs_pixel<KK>(g, BP * bx + pix + PPT * i, px) && bxok;
+            const bool okd = wgs_pixel<KK>(g, BP * bd + pix + PPT * i, pd) && bdok;
+            const unsigned ox = okx ? (unsigned)(px * g.ldx + ci0 + 8 * ch) * 2u : 0u;
+            const unsigned od = okd ? (unsigned)(pd * g.lddy + co0 + 8 * ch) * 2u : 0u;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const bool ok = okx && ci0 + 32 * j + 8 * ch < g.Cin;
+                m |= (unsigned)ok << (i * NI + j);
+                ax[i * NI + j] = *(const u32x4 *)(xb + (ok ? ox + 64u * j : 0u));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool ok = okd && co0 + 32 * j + 8 * ch < g.cout8;
+                m |= (unsigned)ok << (16 + i * NJ + j);
+                ad[i * NJ + j] = *(const u32x4 *)(db + (ok ? od + 64u * j : 0u));
+            }
+        }
+        mko = m;
+    };
+    // ring cursors of iteration n, advanced by one block per iteration (wave-uniform: scalar registers, no division in the loop)
+    const int nfirst = j0 - 2 * g.HB - 1;
+    int st_x = wgs_mod(nfirst + g.HB + 1, nX) * BP, st_d = wgs_mod(nfirst + 1, nD) * BP;     // where S(n) stores
+    int cd = wgs_mod(nfirst, nD) * BP;                                                        // dy block n
+    int cx[KK];                                                                               // x position BP n + off(tap)
+#pragma unroll
+    for (int u = 0; u < KK; ++u) cx[u] = wgs_mod(BP * nfirst + g.tapoff[u], g.RX);
+    auto advance = [&]() __attribute__((always_inline)) {
+        st_x += BP; if (st_x >= g.RX) st_x -= g.RX;
+        st_d += BP; if (st_d >= g.RD) st_d -= g.RD;
+        cd += BP; if (cd >= g.RD) cd -= g.RD;
+#pragma unroll
+        for (int u = 0; u < KK; ++u) { cx[u] += BP; if (cx[u] >= g.RX) cx[u] -= g.RX; }
+    };
+    // S(n): x block n + HB + 1 and dy block n + 1 go to their ring slots (zeros where the mask says so)
+    auto store = [&](const u32x4 (&ax)[NPIX * NI], const u32x4 (&ad)[NPIX * NJ], unsigned mki) __attribute__((always_inline)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NPIX; ++i) {
+            const int sx = st_x + pix + PPT * i, sd = st_d + pix + PPT * i;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const u32x4 v = (mki >> (i * NI + j)) & 1u ? ax[i * NI + j] : z;
+                unsigned char *p = Xs + (j * RXp + sx) * 64 + ch * 16;
+                *(u32x4 *)p = v;
+                if (sx < 16) *(u32x4 *)(p + g.RX * 64) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                *(u32x4 *)(Ds + (j * g.RD + sd) * 64 + ch * 16) = (mki >> (16 + i * NJ + j)) & 1u ? ad[i * NJ + j] : z;
+        }
+    };
+
+    // ---- fragments: transposing reads (lane = 16 gi + 4 q + p addresses position 8 (lane >> 5) + q [+ 4], channels
+    // 16 (gi & 1) + 4 p .. + 3 of its wave's plane; it receives the MFMA row / column lane & 31, k = 8 (lane >> 5) + 0..7) -----
+    const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3, lh = lane >> 5;
+    const int lane_off = (8 * lh + qq) * 64 + (16 * (gi & 1) + 4 * pp) * 2;
+    const unsigned char *a_lane = Xs + wi * RXp * 64 + lane_off;
+    const unsigned char *b_lane = Ds + wj * g.RD * 64 + lane_off;
+    typedef __attribute__((address_space(3))) bf16x4 *lds_b4;
+    auto frag = [&](const unsigned char *p) __attribute__((always_inline)) {
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(p));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(p + 256));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto a_ptr = [&](int u, int st) __attribute__((always_inline)) {
+        int sl = cx[u] + 16 * st;
+        if (sl >= g.RX) sl -= g.RX;
+        return a_lane + sl * 64;
+    };
+    // this wave's steps of the block; the x fragment of tap u + 1 is requested before the MFMA of tap u
+    auto compute = [&]() __attribute__((always_inline)) {
+        for (int st = wk; st < BP / 16; st += WK) {
+            const bf16x8 bv = frag(b_lane + (cd + 16 * st) * 64);
+            bf16x8 av = frag(a_ptr(0, st));
+#pragma unroll
+            for (int u = 0; u < KK; ++u) {
+                bf16x8 an = av;
+                if (u + 1 < KK) an = frag(a_ptr(u + 1, st));
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[u], 0, 0, 0);
+                av = an;
+            }
+        }
+    };
+
+    // ---- pipeline: iteration n stores what was requested PD - 1 iterations earlier, requests PD - 1 blocks ahead, multiplies
+    // block n (from n = j0 on; the first 2 HB + 1 iterations only fill the x halo).  Unrolled PD times: static register sets. --
+#pragma unroll
+    for (int p = 0; p < PD - 1; ++p) issue(nfirst - (PD - 1) + p, rx[p], rd[p], mk[p]);
+    for (int n = nfirst; n < j1; n += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            if (n + p < j1) {
+                issue(n + p, rx[(p + PD - 1) % PD], rd[(p + PD - 1) % PD], mk[(p + PD - 1) % PD]);
+                store(rx[p], rd[p], mk[p]);
+                __syncthreads();
+                if (n + p >= j0) compute();
+                advance();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the WK pixel groups of a slab are summed into the wk == 0 waves through LDS, TG taps per round, in a fixed order ----
+    if (WK > 1) {
+        float *red = (float *)smem;                 // [NI * NJ][TG][32][33]
+        float *r = red + (size_t)((wj * NI + wi) * TG) * 32 * 33;
+        const int lr = lane & 31;
+#pragma unroll
+        for (int u0 = 0; u0 < KK; u0 += TG) {
+            for (int w = 1; w < WK; ++w) {
+                if (wk == w) {
+#pragma unroll
+                    for (int u = 0; u < TG; ++u)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) r[(u * 32 + yh_mfma_row(q, lh)) * 33 + lr] = acc[u0 + u][q];
+                }
+                __syncthreads();
+                if (wk == 0) {
+#pragma unroll
+                    for (int u = 0; u < TG; ++u)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[u0 + u][q] += r[(u * 32 + yh_mfma_row(q, lh)) * 33 + lr];
+                }
+                __syncthreads();
+            }
+        }
+        if (wk != 0) return;
+    }
+    // slab write [tap][ci][co] fp32 straight from the accumulators (a register row = 32 consecutive output channels)
+    float *slab = g.ws + (size_t)split * KK * g.Cin * g.Cout;
+    const int co = co0 + 32 * wj + (lane & 31);
+#pragma unroll
+    for (int u = 0; u < KK; ++u)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ci = ci0 + 32 * wi + yh_mfma_row(q, lh);
+            if (ci < g.Cin && co < g.Cout) slab[((size_t)u * g.Cin + ci) * g.Cout + co] = acc[u][q];
+        }
+}
+
+struct WgsPlan {
+    WgS g;
+    int NI, NJ, KK, nsplit, ntiles;
+    size_t smem;
+};
+
+void plan_wgs(WgsPlan &pl, int B, int H, int W, int Cin, int Cout, int k) {
+    WgS &g = pl.g;
+    g.Cin = Cin; g.Cout = Cout; g.cout8 = (Cout + 7) & ~7;
+    g.H = H; g.W = W; g.pad = k / 2;
+    g.XW = W + 2 * g.pad; g.VH = H + 2 * g.pad;
+    g.Mflat = B * g.VH * g.XW;
+    yh_set_magic((unsigned)g.XW, g.xw_magic, g.xw_shift);
+    yh_set_magic((unsigned)g.VH, g.vh_magic, g.vh_shift);
+    pl.KK = k * k;
+    const int BP = k == 3 ? WgsCfg<9>::BP : WgsCfg<1>::BP;
+    g.nblk_total = cdiv(g.Mflat, BP);
+    // 64-channel tiles read every line whole and once; for the short streams of the 40x40 / 20x20 3x3 layers one input plane
+    // per workgroup (twice the tiles, half the splits and slab bytes) measured 5-15 % faster (tools/wgs_sweep.sh)
+    pl.NI = Cin > 32 && (k == 1 || Cin >= 256 || (g.nblk_total >= 800 && (Cin >= 128 || g.nblk_total >= 1600))) ? 2 : 1;
+    pl.NJ = Cout > 32 ? 2 : 1;
+    {   // the rings must fit the CU's 160 KB (wide rows: a 160-pixel row needs a 912-position x ring)
+        const int hb = k == 1 ? 0 : cdiv(g.XW + 1, BP);
+        auto rings_b = [&](int ni, int nj) { return (size_t)ni * ((2 * hb + 3) * BP + 16) * 64 + (size_t)nj * 3 * BP * 64; };
+        if (rings_b(pl.NI, pl.NJ) > 160 * 1024) pl.NI = 1;
+        if (rings_b(pl.NI, pl.NJ) > 160 * 1024) pl.NJ = 1;
+    }
+#ifdef YH_WGS_TUNE
+    if (getenv("YH_WGS_NJ") && Cout > 32) pl.NJ = atoi(getenv("YH_WGS_NJ"));
+    if (getenv("YH_WGS_NI") && Cin > 32) pl.NI = atoi(getenv("YH_WGS_NI"));
+#endif
+    g.n_ci_tiles = cdiv(Cin, 32 * pl.NI);
+    pl.ntiles = g.n_ci_tiles * cdiv(Cout, 32 * pl.NJ);
+    g.HB = k == 1 ? 0 : cdiv(g.XW + 1, BP);
+    g.RX = (2 * g.HB + 3) * BP;
+    g.RD = 3 * BP;
+    for (int u = 0; u < 9; ++u) g.tapoff[u] = k == 3 ? (u / 3 - 1) * g.XW + (u % 3 - 1) : 0;
+    // one (3x3) or two (1x1) workgroups per CU; a split no shorter than twice its halo fill (every split re-reads 2 HB + 1
+    // blocks of x)
+    int want = (k == 3 ? 256 : 512) / pl.ntiles;
+#ifdef YH_WGS_TUNE
+    if (getenv("YH_WGS_SPLITS")) want = atoi(getenv("YH_WGS_SPLITS"));
+#endif
+    if (want < 1) want = 1;
+    int bps = cdiv(g.nblk_total, want);
+    const int min_bps = 2 * (2 * g.HB + 1) + 2;
+    if (bps < min_bps) bps = min_bps;
+    if (bps > g.nblk_total) bps = g.nblk_total;
+    g.blk_per_split = bps;
+    pl.nsplit = cdiv(g.nblk_total, bps);
+    g.ntiles = pl.ntiles;
+    g.nsplit = pl.nsplit;
+    const size_t rings = (size_t)pl.NI * (g.RX + 16) * 64 + (size_t)pl.NJ * g.RD * 64;
+    const int WK = ((k == 3 ? WgsCfg<9>::NT : WgsCfg<1>::NT) / 64) / (pl.NI * pl.NJ);
+    const size_t red = WK > 1 ? (size_t)pl.NI * pl.NJ * (pl.KK == 9 ? 3 : 1) * 32 * 33 * sizeof(float) : 0;
+    pl.smem = rings > red ? rings : red;
+}
+
+template <int KK, int NI, int NJ>
+int launch_wgs(const WgsPlan &pl, hipStream_t st) {
+    auto kern = bf16_wgrad_stream_kernel<KK, NI, NJ>;
+    if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
+    hipLaunchKernelGGL(kern, dim3(pl.nsplit * pl.ntiles), dim3(WgsCfg<KK>::NT), pl.smem, st, pl.g);
+    YH_CHECK_LAUNCH("bf16_wgrad_stream");
+    return 0;
+}
+
+}  // namespace
+
+bool yh_bf16_wgrad_stream_ok(int W, int Cin, int Cout, int k, int s) {
+    // (k = 3: the x ring holds 2 (W + 2) + 2 positions of halo around a block; rows up to 638 pixels fit one 32-channel plane)
+    return s == 1 && (k == 1 || (k == 3 && W <= 600)) && Cin % 8 == 0 && Cin >= 8 && Cout >= 1;
+}
+
+int64_t yh_bf16_wgrad_stream_ws(int B, int H, int W, int Cin, int Cout, int k) {
+    WgsPlan pl{};
+    plan_wgs(pl, B, H, W, Cin, Cout, k);
+    return (int64_t)pl.nsplit * k * k * Cin * Cout;
+}
+
+int yh_bf16_wgrad_stream(const void *x, int ldx, const void *dy, int lddy, float *ws, int64_t ws_floats, int B, int H, int W, int Cin,
+                         int Cout, int k, int *nsplit, hipStream_t st) {
+    WgsPlan pl{};
+    plan_wgs(pl, B, H, W, Cin, Cout, k);
+    YH_REQUIRE(ws_floats >= (int64_t)pl.nsplit * k * k * Cin * Cout, "bf16_wgrad_stream: workspace too small");
+    YH_REQUIRE((int64_t)B * H * W * ldx * 2 < (1ll << 31) && (int64_t)B * H * W * lddy * 2 < (1ll << 31) && pl.g.Mflat < (1 << 29),
+               "bf16_wgrad_stream: tensor exceeds the 32-bit byte-offset range");
+    pl.g.x = (const bf16 *)x; pl.g.dy = (const bf16 *)dy; pl.g.ws = ws; pl.g.ldx = ldx; pl.g.lddy = lddy;
+    *nsplit = pl.nsplit;
+    if (k == 3) {
+        if (pl.NI == 2) return pl.NJ == 2 ? launch_wgs<9, 2, 2>(pl, st) : launch_wgs<9, 2, 1>(pl, st);
+        return pl.NJ == 2 ? launch_wgs<9, 1, 2>(pl, st) : launch_wgs<9, 1, 1>(pl, st);
+    }
+    if (pl.NI == 2) return pl.NJ == 2 ? launch_wgs<1, 2, 2>(pl, st) : launch_wgs<1, 2, 1>(pl, st);
+    return pl.NJ == 2 ? launch_wgs<1, 1, 2>(pl, st) : launch_wgs<1, 1, 1>(pl, st);
+}
