@@ -81,7 +81,7 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_CONV_STEM_FWD, L.OP_BF16_CONV_FWD, L.OP_CONV_NARROW, L.OP_BF16_CONV_NARROW):
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_BF16_CONV_FWD, L.OP_CONV_NARROW, L.OP_BF16_CONV_NARROW):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1

@@ -41,9 +41,20 @@ const char *yh_last_error(void);    /* per host thread */
 typedef struct yh_context yh_context;
 int yh_create(yh_context **out);
 int yh_destroy(yh_context *ctx);          /* waits for the side stream, then frees it; NULL is a no-op */
-/* enable = 0: yh_run executes every op in list order on the caller's stream (default: on, or YH_OVERLAP=0) */
+/* enable = 0: yh_run executes every op in list order on the caller's stream.  Default: on; the environment variable
+ * YH_OVERLAP=0 (read ONCE, by yh_create) makes contexts start with it off (profiling: serialised lanes).
+ *
+ * Environment variables of the whole package -- nothing is read from the environment on a launch path:
+ *   YH_OVERLAP=0      library, per context at yh_create: no side lane (above)
+ *   YH_BF16_STREAM=0  library, once per process: stride-1 bf16 layers on the segment kernels (conv_bf16.hip) instead of the
+ *                     flat-stream kernels (conv_bf16_stream.hip) -- A/B switch
+ *   YH_GENERIC=1      planner (graph.py), when a plan is traced: every convolution on the generic gather-GEMM / wgrad kernels
+ *                     instead of the specialised families (the two product paths cross-check each other in the tests)
+ *   YH_EVAL_FAST=0    planner: eval plans keep every layer on the gather GEMM (no fused Winograd / pointwise forms)
+ *   YH_BENCH_SHAPE / YH_BENCH_DTYPE / YH_BENCH_SIZE   bench.py only: informational shapes, never the reported metric
+ * Diagnostic builds are compile-time: make EXTRA=-DYH_PW_STAMPS | -DYH_WINO_STAMPS | -DYH_BF_STAMPS | -DYH_WGS_TUNE. */
 int yh_context_set_overlap(yh_context *ctx, int enable);
-/* introspection for tests: bound device (-1 = not bound yet), overlap flag (-1 = undecided), raw handles (NULL
+/* introspection for tests: bound device (-1 = not bound yet), overlap flag, raw handles (NULL
  * until the first forked run); any output pointer may be NULL */
 int yh_context_info(const yh_context *ctx, int *device, int *overlap, void **side_stream, void **fork_event,
                     void **join_event);
@@ -124,12 +135,6 @@ int yh_pack_weights_s2m(const float *oihw, float *wbm, int Cout, int Cin, int ld
  * dy1 / dy2: (B,H,W,*) views with the same ld; wb: the two backward packs stacked, rows [0,cout1) then [cout1, cout1+cout2). */
 int yh_conv_bwd_data_pair(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wb, int ldwb,
                           float *dx, int lddx, int B, int H, int W, int Cin, int accumulate, void *stream);
-/* The network's first convolution (3 -> 16 channels, k = 3, s = 2, p = 1, input NHWC4 with ld = 4, forward pack weights
- * [9][4][16]) as a direct VALU kernel: the layer is HBM-bound and K = 27 is too small for the MFMA path.  Same contract as
- * yh_conv_fwd; bn_partials [yh_conv_stem_blocks(B,Hi,Wi)][2][16].  replaces: stem[0] forward, train.py:402-403. */
-int yh_conv_stem_fwd(const float *x, const float *wf, const float *bias, float *y, int ldy, float *bn_partials, int B, int Hi,
-                     int Wi, void *stream);
-int yh_conv_stem_blocks(int B, int Hi, int Wi);
 /* The narrow high-resolution 3x3 layers (16 -> 16 stride 1: the C3 bottleneck at 1/4 resolution; 16 -> 32 stride 2: stem[3]) as
  * a direct convolution on v_mfma_f32_16x16x4_f32: the input halo patch is read from HBM once into LDS, the whole filter sits
  * in registers, 16-wide MFMA tiles (no padding of the 16 output channels).  w: the forward pack [9][Cin][ldw] of
@@ -185,17 +190,6 @@ int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const flo
                      float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
 int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                           int W, int Cin, int Cout, int accumulate, void *stream);
-/* Backward-data kernels that ALSO produce the BatchNorm-backward sums of the layers whose activation gradient they
- * finish writing (so the separate pass yh_bn_silu_bwd_reduce over dOut and y disappears for those layers).  bn_table:
- * DEVICE array of n_bn (<= 8) 48-byte records { const float *y, *coef; float *partials; int32 col0, ncol, ldy, C, 0, 0 }:
- * output columns [col0, col0 + ncol) of dx are the C = ncol channels of a producer whose pre-BN output is y (pixel
- * stride ldy) and whose forward coefficients are coef (yh_bn_finalize); partials receives
- * [rows][2][C] with rows = yh_conv_wino_blocks(B,H,W) resp. yh_conv_pw_blocks(M, cout1 + cout2, Cin), to be handed to
- * yh_bn_silu_bwd_apply as its (partials, nblk).  Only valid when this call writes the FINAL value of those columns. */
-int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H, int W,
-                             int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream);
-int yh_conv_pw_bwd_data_bn(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw, float *dx,
-                           int lddx, int64_t M, int Cin, int accumulate, const void *bn_table, int n_bn, void *stream);
 /* Backward-weight in the Winograd domain (Cin % 32 == 0, Cout % 32 == 0, even H, W): dw (OIHW) = the same sum as
  * yh_conv_bwd_weight for k = 3, s = 1, deterministic (fixed-order reduction of per-workgroup [9][Cin][Cout] slabs
  * through ws, ws_floats >= yh_conv_wino_bwd_weight_ws(...)). */
@@ -229,7 +223,6 @@ int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const floa
 int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw, const float *bias1, float *y1, int ldy1,
                     float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2, int cout2,
                     int64_t M, int Cin, void *stream);
-int yh_conv_pw_bwd_data_bn_rows(int64_t M, int K, int Cin);   /* rows of the partial sums yh_conv_pw_bwd_data_bn writes */
 int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw, float *dx,
                         int lddx, int64_t M, int Cin, int accumulate, void *stream);
 /* Backward-weight: dw[co][ci][kh][kw] = sum_pixels x * dy, deterministic two-stage reduction

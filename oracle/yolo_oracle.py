@@ -67,18 +67,26 @@ class _Net:
     used to derive the bf16 tests' tolerances (how far a correct bf16-storage pipeline drifts from fp32); the fp32 mode
     is the pinned restatement of the reference."""
 
-    def __init__(self, P: Dict[str, torch.Tensor], training: bool, storage: str = "f32"):
-        self.P, self.training, self.bf16 = P, training, storage == "bf16"
+    SITES = ("img", "w", "y", "dy", "a", "da", "dhead")     # the places where the bf16 path stores a rounded value
 
-    def q(self, t, fwd=True, bwd=True):
-        return _RoundBf16.apply(t, fwd, bwd) if self.bf16 else t
+    def __init__(self, P: Dict[str, torch.Tensor], training: bool, storage="f32"):
+        """storage: "f32", "bf16" (every site) or a collection of SITES names (ablations: which rounding costs what)."""
+        self.P, self.training = P, training
+        self.sites = frozenset(self.SITES) if storage == "bf16" else frozenset() if storage == "f32" else frozenset(storage)
+        assert self.sites <= frozenset(self.SITES), storage
+        self.bf16 = bool(self.sites)
+
+    def q(self, t, fwd=None, bwd=None):
+        """fwd / bwd: site names (or None) of the forward value / of its gradient."""
+        f, b = fwd in self.sites, bwd in self.sites
+        return _RoundBf16.apply(t, f, b) if (f or b) else t
 
     def _w(self, key):                       # the bf16 weight pack: rounded copy, fp32 master gradient
-        return self.q(self.P[key], True, False)
+        return self.q(self.P[key], "w", None)
 
     def _bn_silu(self, y, bn, residual=None):
         P = self.P
-        y = self.q(y)                        # stored pre-BN output (statistics are those of the stored values); dY stored
+        y = self.q(y, "y", "dy")             # stored pre-BN output (statistics are those of the stored values); dY stored
         out = F.batch_norm(y, P[f"{bn}.running_mean"], P[f"{bn}.running_var"],
                            P[f"{bn}.weight"], P[f"{bn}.bias"], self.training, BN_MOMENTUM, BN_EPS)
         if self.training and f"{bn}.num_batches_tracked" in P:
@@ -86,7 +94,7 @@ class _Net:
         a = F.silu(out)
         if residual is not None:
             a = residual + a
-        return self.q(a)                     # stored activation; its gradient (sum over consumers) stored
+        return self.q(a, "a", "da")          # stored activation; its gradient (sum over consumers) stored
 
     def cbs(self, x, name, stride=1, residual=None):
         """ConvBlock = bias-free conv -> BN -> SiLU (train.py:253-265); padding = k//2."""
@@ -124,14 +132,14 @@ class _Net:
         """CB3x3, CB3x3, Conv1x1(+bias) (train.py:452-466)."""
         x = self.cbs(self.cbs(x, f"{name}.0"), f"{name}.1")
         o = F.conv2d(x, self._w(f"{name}.2.weight"), self.P[f"{name}.2.bias"])
-        return self.q(o, False, True)        # fp32 head output, bf16 head gradient
+        return self.q(o, None, "dhead")      # fp32 head output, bf16 head gradient
 
 
 def forward(P: Dict[str, torch.Tensor], x: torch.Tensor, num_classes: int,
             training: bool = True, storage: str = "f32") -> List[torch.Tensor]:
     """YOLO.forward (train.py:568-632): NCHW image batch -> three (B,G,G,3,5+nc) tensors."""
     n = _Net(P, training, storage)
-    x = n.q(x, True, False)
+    x = n.q(x, "img", None)
     up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
     # backbone (train.py:572-576)
     s = n.inline(n.inline(x, "stem.0", "stem.1", 2), "stem.3", "stem.4", 2)

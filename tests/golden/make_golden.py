@@ -203,6 +203,11 @@ def gen_model(tag, nc, S, B, lr=1e-3):
         out[f"pred{s}_sum"] = np.array([float(p.double().sum()), float(p.double().abs().sum())])
         idx = sample_idx(p.numel(), 1024, 50 + s)
         out[f"pred{s}_idx"], out[f"pred{s}_sample"] = idx, npy(p.reshape(-1)[idx])
+        # decoded boxes of the reference's own forward at sampled cells (decode_predictions with img_size = the model's,
+        # as predict() calls it, train.py:1154): fp32 boxes are held to 1e-4 relative end to end
+        dec = ref.decode_predictions(p.detach(), m.anchors[s], S).reshape(-1, 5 + nc)
+        cells = sample_idx(dec.shape[0], 512, 90 + s)
+        out[f"dec{s}_cells"], out[f"dec{s}_boxes"] = cells, npy(dec[cells, :4])
     names = [n for n, _ in m.named_parameters()]
     out["param_names"] = np.array(names)
     out["grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])

@@ -151,9 +151,9 @@ def test_contexts_are_independent_handles():
     from yolo_from_scratch_amd import _lib as L
     a, b = L.Context(), L.Context()
     assert a.handle.value != b.handle.value
-    assert a.info() == {"device": -1, "overlap": -1, "side_stream": None, "fork_event": None, "join_event": None}
+    assert a.info() == {"device": -1, "overlap": 1, "side_stream": None, "fork_event": None, "join_event": None}   # YH_OVERLAP is read at yh_create
     a.set_overlap(False)
-    assert a.info()["overlap"] == 0 and b.info()["overlap"] == -1          # b untouched
+    assert a.info()["overlap"] == 0 and b.info()["overlap"] == 1           # b untouched
     b.set_overlap(True)
     assert a.info()["overlap"] == 0 and b.info()["overlap"] == 1
     # an empty list, and a list of lane markers only, run without touching a device

@@ -14,8 +14,15 @@ places) and the tests measure its drift next to the HIP path's:
     step differ by 0.8 % in the box term at batch 1 (-0.7 % vs -1.5 % against fp32; total loss -0.4 % both);
   * weight gradients are the residue of heavily cancelling sums (BatchNorm zero-means every layer's input, the
     objectness gradient is almost constant over 10^5..10^6 cells), so 0.2 % storage noise becomes cosines of ~0.995
-    (heads), ~0.985 (neck) and ~0.95 (backbone, behind the max-pools whose argmax ties multiply in bf16) against fp32 --
-    in the emulation.  The HIP path must reach the emulation's cosine minus 0.03 on every tensor, and 0.90 absolutely
+    (heads), ~0.985 (neck) and ~0.95 (backbone) against fp32 -- in the emulation.  WHICH rounding does it was measured
+    site by site (tools/bf16_ablate.py, round 3): rounding only the gradient side (dY, dA, the head gradient) leaves every
+    cosine at 1.0000; the loss of agreement comes from the FORWARD values alone -- the image alone 0.979, the weight packs
+    alone 0.960, pre-BN outputs 0.968, activations 0.964 (backbone means), all together 0.913 -- i.e. the gradient of the
+    freshly INITIALISED network is ill-conditioned with respect to 2^-9 perturbations of its forward pass, and that is a
+    property of the starting point, not of the arithmetic: after 30 / 60 Adam steps the same emulation agrees with fp32 at
+    cosine >= 0.977 / 0.983 on every weight tensor (mean 0.991 / 0.994) and 2.4e-3 in the loss
+    (test_bf16_gradients_agree_after_warmup, test_bf16_trajectory_tracks_fp32 below hold the HIP path to that).
+    At initialisation the HIP path must reach the emulation's cosine minus 0.03 on every tensor, and 0.90 absolutely
     (0.06 / 0.85, and 20 % instead of 10 % on the norm, for the 64..256-entry BatchNorm vectors: noisier statistics);
   * the global gradient norm within 5 %.
 The seven conv biases in front of BatchNorm (quirk Q2: true gradient 0) are excluded as in the fp32 tests."""
@@ -146,6 +153,69 @@ def test_bf16_training_learns_and_is_reproducible():
     hist = runs[0][0]
     assert torch.isfinite(hist).all()
     assert float(hist[-10:, 0].mean()) < 0.5 * float(hist[:5, 0].mean())                     # overfits the fixed batch
+
+
+def _stream_batch(y, i, nc, S, B):
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1000 + i)).cuda()
+    return x, [t.cuda() for t in y.synthetic_targets(B, nc, S, 8, 2000 + i)]
+
+
+def test_bf16_gradients_agree_after_warmup():
+    """VERDICT r2 item 7.  The 0.90-0.95 cosines at initialisation are the conditioning of the random network, not a defect
+    of the bf16 path (file header): the SAME comparison 100 Adam steps into training -- bf16 and fp32 HIP gradients at
+    identical weights on a fresh batch -- must agree at cosine >= 0.98 on every weight tensor, >= 0.99 on average, and
+    2e-3 relative in the loss.  Measured on MI355X along the way (tools/bf16_grad_agreement.py; worst / mean cosine, loss
+    gap): step 0: 0.932 / 0.965, 3.9e-3; 20: 0.976 / 0.989; 40: 0.964 / 0.995; 60: 0.926 / 0.975 (the first ~60 steps are
+    the noisy phase in which single layers' gradients swing); 100: 0.9935 / 0.9988, 4.0e-4; 150: 0.9926 / 0.9979, 4.2e-4."""
+    y = api()
+    nc, S, B = 3, 320, 4
+    torch.manual_seed(0)
+    m = y.YOLO(num_classes=nc, img_size=S).cuda()
+    tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0, dtype="f32")
+    for i in range(100):
+        tr.step(*_stream_batch(y, i, nc, S, B))
+    x, tg = _stream_batch(y, 999, nc, S, B)
+    names = [n for n, p in m.named_parameters() if p.dim() == 4]
+    res = {}
+    for dtype in ("f32", "bf16"):
+        m.set_compute_dtype(dtype)
+        m.train()
+        m.zero_grad()
+        out = y.yolo_loss_multiscale(m(x), tg, m.anchors, nc)
+        out[0].backward()
+        res[dtype] = (float(out[0]), {n: p.grad.detach().reshape(-1).double().clone() for n, p in m.named_parameters() if n in names})
+    m.set_compute_dtype("f32")
+    assert abs(res["bf16"][0] - res["f32"][0]) <= 2e-3 * abs(res["f32"][0])
+    cos = {n: _cos(res["f32"][1][n], res["bf16"][1][n]) for n in names if float(res["f32"][1][n].norm()) > 0}
+    assert len(cos) >= 55
+    worst = min(cos, key=cos.get)
+    assert cos[worst] >= 0.98, (worst, cos[worst])
+    assert sum(cos.values()) / len(cos) >= 0.99
+
+
+def test_bf16_trajectory_tracks_fp32():
+    """300 training steps on the same seeded synthetic stream (fresh batch every step: no overfitting), fp32 and bf16 from the
+    same initial weights: the bf16 loss curve stays within 3 % of the fp32 one (means over windows of 50 steps; single
+    steps are noisy because every batch is new) and ends within 2 %; both decrease."""
+    y = api()
+    nc, S, B, steps = 2, 160, 8, 300
+    curves = {}
+    for dtype in ("f32", "bf16"):
+        torch.manual_seed(0)
+        m = y.YOLO(num_classes=nc, img_size=S).cuda()
+        tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0, dtype=dtype)
+        hist = []
+        for i in range(steps):
+            hist.append(tr.step(*_stream_batch(y, i, nc, S, B))[:1].clone())
+        curves[dtype] = torch.cat(hist).cpu().double()
+        del tr, m
+    a, b = curves["f32"], curves["bf16"]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    wa, wb = a.view(-1, 50).mean(1), b.view(-1, 50).mean(1)
+    assert float(wa[-1]) < 0.8 * float(wa[0]) and float(wb[-1]) < 0.8 * float(wb[0])          # both learn
+    gap = ((wb - wa).abs() / wa).max()
+    assert float(gap) <= 0.03, (wa.tolist(), wb.tolist())
+    assert abs(float(wb[-1]) - float(wa[-1])) <= 0.02 * float(wa[-1])
 
 
 @pytest.mark.parametrize("nc,S,B", [(80, 640, 64), (80, 1280, 16)])

@@ -78,6 +78,11 @@ def test_full_model_autograd_path_matches_reference_golden(tag, nc, S):
     for s, p in enumerate(preds):
         close(p.detach().cpu().reshape(-1)[T(g[f"pred{s}_idx"])], g[f"pred{s}_sample"], 1e-3, 2e-4)
         close([float(p.double().sum())], g[f"pred{s}_sum"][:1], 1e-4, 1e-2)
+        # north_star: "fp32 boxes within 1e-4 relative" -- the HIP forward decoded by the HIP decode kernel against the boxes
+        # the REFERENCE decodes from its own forward (sampled cells of every scale; 1e-6 absolute floor: normalised
+        # coordinates of cells in the first grid column / row are ~1e-3)
+        dec = y.decode_predictions(p.detach(), m.anchors[s], S).reshape(-1, 5 + nc)[T(g[f"dec{s}_cells"]).cuda(), :4]
+        close(dec.cpu(), g[f"dec{s}_boxes"], 1e-4, 1e-6)
     tot.backward()
     names = list(g["param_names"])
     params = dict(m.named_parameters())
@@ -470,8 +475,7 @@ def test_full_size_step_properties(monkeypatch):
     tg = [t.cuda() for t in y.synthetic_targets(B, nc, S, 8, 32)]
 
     def run(generic):
-        for k in ("YH_WINO", "YH_PW", "YH_PWG", "YH_STEM", "YH_S2M"):
-            monkeypatch.setenv(k, "0" if generic else "1")
+        monkeypatch.setenv("YH_GENERIC", "1" if generic else "0")
         torch.manual_seed(0)
         m = y.YOLO(num_classes=nc, img_size=S).cuda()
         tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
@@ -494,23 +498,3 @@ def test_full_size_step_properties(monkeypatch):
             checked += 1
     assert checked > 150
 
-
-def test_bn_backward_sums_in_dgrad_epilogue_match_the_reduce_pass(monkeypatch):
-    """YH_BN_EPI=1 (off by default: slower) moves the BatchNorm-backward sums into the epilogue of the backward-data GEMM that
-    finishes a layer's activation gradient (yh_conv_wino_bwd_data_bn / yh_conv_pw_bwd_data_bn): same gradients as the
-    separate reduce pass to fp32 summation-order noise."""
-    y = api()
-    x = torch.rand(2, 3, 320, 320, generator=torch.Generator().manual_seed(41)).cuda()
-    tg = [t.cuda() for t in y.synthetic_targets(2, 1, 320, 8, 42)]
-    res = []
-    for epi in ("0", "1"):
-        monkeypatch.setenv("YH_BN_EPI", epi)
-        torch.manual_seed(0)
-        m = y.YOLO(num_classes=1, img_size=320).cuda()
-        tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0)
-        loss = tr.step(x, tg)[:4].cpu().clone()
-        res.append((loss, tr.flat_g.clone(), getattr(m._plan_for(x), "bn_epilogue_layers", 0)))
-    assert res[0][2] == 0 and res[1][2] >= 30            # most C3-internal layers are covered
-    assert torch.equal(res[0][0], res[1][0])              # the forward is untouched
-    d = (res[0][1] - res[1][1]).abs().max().item()
-    assert d <= 2e-4 * res[0][1].abs().max().item()

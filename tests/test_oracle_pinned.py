@@ -274,6 +274,9 @@ def test_full_model_step_matches_reference(tag, nc, S):
     close([float(tot), float(b), float(o), float(c)], g["scalars"], 2e-5, 1e-6)
     for s, p in enumerate(preds):
         close(p.detach().reshape(-1)[T(g[f"pred{s}_idx"])], g[f"pred{s}_sample"], 1e-3, 1e-4)
+        # decoded boxes of the whole forward at the reference's sampled cells: north_star's "fp32 boxes within 1e-4 relative"
+        dec = orc.decode(p.detach(), orc.anchors_of(P)[s], S).reshape(-1, 5 + nc)[T(g[f"dec{s}_cells"]), :4]
+        close(dec, g[f"dec{s}_boxes"], 1e-4, 1e-6)
     tot.backward()
     gn = np.array([float(P[n].grad.double().norm()) for n in names])
     q2 = {"stem.0.bias", "stem.3.bias", "backbone_p3.1.bias", "backbone_p4.0.bias", "backbone_p5.0.bias",

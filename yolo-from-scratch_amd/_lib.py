@@ -67,8 +67,6 @@ _SIGS = {
     "yh_conv_fwd_fused_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "yh_conv_bwd_data_s2m": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pack_weights_s2m": (i32, [c_fp, c_fp, i32, i32, i32, c_fp]),
-    "yh_conv_stem_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
-    "yh_conv_stem_blocks": (i32, [i32, i32, i32]),
     "yh_conv_narrow_ok": (i32, [i32, i32, i32, i32]),
     "yh_conv_narrow_blocks": (i32, [i32, i32, i32, i32, i32]),
     "yh_conv_narrow_dgrad_s2_ok": (i32, [i32, i32]),
@@ -82,14 +80,11 @@ _SIGS = {
     "yh_conv_narrow": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_pw_pack_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_pw_blocks": (i32, [i64, i32, i32]),
-    "yh_conv_pw_bwd_data_bn_rows": (i32, [i64, i32, i32]),
     "yh_conv_pw_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i64, i32, i32, c_fp]),
     "yh_conv_pw_fwd2": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, c_fp]),
     "yh_conv_pw_bwd_data": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i64, i32, i32, c_fp]),
     "yh_conv_pw_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i64, i32, i32, c_fp]),
     "yh_conv_pw_bwd_weight_ws": (i64, [i64, i32, i32]),
-    "yh_conv_wino_bwd_data_bn": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp, i32, c_fp]),
-    "yh_conv_pw_bwd_data_bn": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i64, i32, i32, c_fp, i32, c_fp]),
     "yh_conv_wino_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_data_pair": (i32, [c_fp, i32, c_fp, i32, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),

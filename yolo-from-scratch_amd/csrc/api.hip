@@ -77,18 +77,18 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_WINO_FWD:
             return yh_conv_wino_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3],
                                     i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], st);
-        case YH_OP_CONV_WINO_BWD_DATA:      /* p[3] / i[9]: optional BatchNorm-backward table */
-            return yh_conv_wino_bwd_data_bn((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
-                                            i[5], i[6], i[7], i[8], p[3], i[9], st);
+        case YH_OP_CONV_WINO_BWD_DATA:
+            return yh_conv_wino_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
+                                         i[5], i[6], i[7], i[8], st);
         case YH_OP_CONV_WINO_BWD_WEIGHT:
             return yh_conv_wino_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
                                            o.l[0], i[2], i[3], i[4], i[5], i[7], st);
         case YH_OP_CONV_PW_BWD_WEIGHT:      /* same argument slots as YH_OP_CONV_BWD_WEIGHT */
             return yh_conv_pw_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
                                          o.l[0], (int64_t)i[2] * i[3] * i[4], i[5], i[7], st);
-        case YH_OP_CONV_STEM_FWD:           /* same argument slots as YH_OP_CONV_FWD */
-            return yh_conv_stem_fwd((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[2], (float *)p[4],
-                                    i[3], i[4], i[5], st);
+        case YH_OP_CONV_STEM_FWD:           /* retired (the first layer runs on narrow_conv_kernel); the enum slot stays for ABI stability */
+            yh_set_error("yh_run: YH_OP_CONV_STEM_FWD was retired in round 3");
+            return YH_E_UNSUPPORTED;
         case YH_OP_PACK_WEIGHTS_S2M:
             return yh_pack_weights_s2m((const float *)p[0], (float *)p[1], i[0], i[1], i[2], st);
         case YH_OP_CONV_BWD_DATA_S2M:       /* same argument slots as YH_OP_CONV_BWD_DATA */
@@ -103,9 +103,9 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */
             return yh_conv_pw_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
                                   (float *)p[4], (int64_t)i[3] * i[4] * i[5], i[6], i[7], st);
-        case YH_OP_CONV_PW_BWD_DATA:        /* p: dy1, dy2 | NULL, wq, dx, bn table | NULL;  i: cout1, cout2, lddy, ldw, lddx, B, H, W, Cin, accumulate, n_bn */
-            return yh_conv_pw_bwd_data_bn((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
-                                          (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], p[4], i[10], st);
+        case YH_OP_CONV_PW_BWD_DATA:        /* p: dy1, dy2 | NULL, wq, dx;  i: cout1, cout2, lddy, ldw, lddx, B, H, W, Cin, accumulate */
+            return yh_conv_pw_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
+                                       (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], st);
         case YH_OP_NOP:
             return 0;
         case YH_OP_CONV_NARROW:
@@ -207,6 +207,21 @@ int yh_ensure_dyn_smem(const void *fn, size_t bytes) {
     return 0;
 }
 
+// ---- the library's environment switches: read ONCE per process, never on a launch path --------------------------------
+// YH_BF16_STREAM=0   route the stride-1 bf16 layers through the segment kernels of conv_bf16.hip instead of the flat-stream
+//                    kernels of conv_bf16_stream.hip (A/B switch)
+// (YH_OVERLAP is per context: yh_create.)  Everything else that used to be an environment knob is a constant now; diagnostic
+// builds (in-kernel stamps, tile sweeps) are compile-time: make EXTRA=-DYH_..._STAMPS / -DYH_WGS_TUNE.
+static std::once_flag g_env_once;
+static int g_bf16_stream = 1;
+int yh_env_bf16_stream() {
+    std::call_once(g_env_once, [] {
+        const char *e = getenv("YH_BF16_STREAM");
+        g_bf16_stream = (e && e[0] == '0') ? 0 : 1;
+    });
+    return g_bf16_stream;
+}
+
 // ---- execution context ("no global mutable state besides the explicit handle") ---------------------------
 // Weight-gradient work (backward-weight GEMMs, bias column sums) depends only on dY and on saved activations, never on
 // the rest of the backward chain, and nothing but the optimiser reads its results.  yh_run therefore forks those ops
@@ -216,7 +231,7 @@ int yh_ensure_dyn_smem(const void *fn, size_t bytes) {
 // current at its first forked run; a context serves one host thread at a time, distinct contexts are independent.
 struct yh_context {
     int device = -1;            // bound lazily, at the first run that needs the side lane
-    int overlap = -1;           // -1: take YH_OVERLAP from the environment at first use
+    int overlap = 1;            // YH_OVERLAP=0 (read ONCE, at yh_create) or yh_context_set_overlap(ctx, 0): run every op in list order
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
@@ -225,6 +240,8 @@ extern "C" int yh_create(yh_context **out) {
     YH_REQUIRE(out, "yh_create: null output");
     *out = new (std::nothrow) yh_context();
     YH_REQUIRE(*out, "yh_create: out of memory");
+    const char *e = getenv("YH_OVERLAP");           // the library's environment switches are read here and in yh_env_once()
+    (*out)->overlap = (e && e[0] == '0') ? 0 : 1;
     return 0;
 }
 
@@ -264,23 +281,13 @@ extern "C" int yh_context_info(const yh_context *ctx, int *device, int *overlap,
 // 1 = the side lane is usable for this run, 0 = run everything in list order on the caller's stream, < 0 = error
 static int side_ready(yh_context *ctx) {
     if (!ctx) return 0;
-    if (ctx->overlap < 0) {
-        const char *e = getenv("YH_OVERLAP");
-        ctx->overlap = (e && e[0] == '0') ? 0 : 1;
-    }
     if (!ctx->overlap) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (!ctx->side) {
-        // YH_SIDE_PRIORITY=low|high: experiment knob.  A low-priority side lane measured 22.21 -> 22.12 ms/step in training
-        // (noise level) but a captured hipGraph with mixed-priority nodes replays 2x slower (2.4 -> 4.8 ms at bs=1), so the
-        // default is an ordinary stream.
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = numerically greatest = lowest priority
-        const char *pr = getenv("YH_SIDE_PRIORITY");
-        hipError_t e = (pr && (pr[0] == 'l' || pr[0] == 'h'))
-                           ? hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, pr[0] == 'l' ? lo : hi)
-                           : hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+        // (an ordinary stream: a low-priority side lane measured 22.21 -> 22.12 ms/step in training -- noise -- and a captured
+        // hipGraph with mixed-priority nodes replays 2x slower, 2.4 -> 4.8 ms at bs=1)
+        hipError_t e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
         if (e != hipSuccess || hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming) != hipSuccess) {
             if (ctx->fork) (void)hipEventDestroy(ctx->fork);

@@ -9,6 +9,8 @@
 void yh_set_error(const char *fmt, ...);
 // opt a kernel into `bytes` of dynamic LDS on the current device (api.hip: mutex-guarded (device, kernel) table)
 int yh_ensure_dyn_smem(const void *fn, size_t bytes);
+// environment switches of the library, read once per process (api.hip)
+int yh_env_bf16_stream();
 
 // Pointers that are SELECTED at run time (tensor A or tensor B, the input or a zero page, a table entry) lose their address
 // space and compile to FLAT loads / stores.  A flat access counts on vmcnt AND lgkmcnt and may retire out of order, so every
@@ -61,26 +63,6 @@ __device__ __forceinline__ float yh_sigmoid(float x) { return 1.0f / (1.0f + exp
 // passes, which are otherwise VALU-bound on the sigmoid (0.9 ms of pure VALU time in the backward reduce at bs=64).
 // Saturates correctly (exp -> inf gives 0, exp -> 0 gives 1); the loss and the detection threshold keep yh_sigmoid.
 __device__ __forceinline__ float yh_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-// BatchNorm-backward statistics folded into the epilogue of the kernel that writes the LAST contribution to an activation
-// gradient (a backward-data GEMM): for output columns [col0, col0 + ncol) -- the channels of one producer layer -- the
-// kernel also loads that layer's pre-BN output y and accumulates, per channel, sum(dz) and sum(dz * xhat) with
-// dz = dOut * silu'(y * scale + shift), i.e. exactly what bn_silu_bwd_reduce_kernel computes in a separate pass over dOut
-// and y.  part: [partial rows of the writing kernel][2][C].  48-byte records in device memory.
-struct YhBnBwdEntry {
-    const float *y, *coef;
-    float *part;
-    int col0, ncol, ldy, C;
-    int pad0, pad1;
-};
-
-__device__ __forceinline__ void yh_bn_bwd_accum(float v, float yv, float sc, float sh, float mu, float is, float &s1, float &s2) {
-    const float z = yv * sc + sh;
-    const float sg = yh_sigmoid_fast(z);
-    const float dz = v * (sg * (1.f + z * (1.f - sg)));
-    s1 += dz;
-    s2 += dz * ((yv - mu) * is);
-}
 
 // 64-lane butterfly sum; every lane ends with the total.
 __device__ __forceinline__ float wave_sum(float v) {

@@ -28,10 +28,7 @@ namespace {
 
 // YH_BF16_STREAM=0 (read once): route the stride-1 layers through the segment kernels of this file instead of the flat-stream
 // kernels of conv_bf16_stream.hip (A/B switch)
-bool use_stream() {
-    static const bool on = !(getenv("YH_BF16_STREAM") && atoi(getenv("YH_BF16_STREAM")) == 0);
-    return on;
-}
+bool use_stream() { return yh_env_bf16_stream() != 0; }
 
 constexpr int BK = 64;                 // k per chunk = 8 octets of 8 bf16 (16 bytes)
 constexpr int A_STRIDE = BK * 2 + 16;  // bytes per A-tile row: 144 -> the 16 rows of a ds_read_b128 lane group hit 16 distinct bank quads
@@ -806,8 +803,7 @@ int plan_wgrad(WgradPlan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, i
     YH_REQUIRE(pl.smem <= 160 * 1024, "bf16_wgrad: LDS footprint %zu too large", pl.smem);
     // split count: one workgroup per CU -- every workgroup pays a fixed epilogue (its whole [taps][ci][co] slab through LDS to
     // HBM, then the reduction re-reads it): with 1024 splits the 3x3 layers moved 300 MB of slabs each, 5.8 ms per step
-    static const int target = getenv("YH_BF16_WGRAD_BLOCKS") ? atoi(getenv("YH_BF16_WGRAD_BLOCKS")) : 256;
-    int want = target / pl.ntiles;
+    int want = 256 / pl.ntiles;      // 128 / 192 / 256 / 384 / 512 / 768 workgroups measured 12.0 / 10.75 / 10.80 / 10.93 / 11.10 / 11.39 ms per step
     if (want < 1) want = 1;
     if (want > g.nseg_total) want = g.nseg_total;
     g.segs_per_split = cdiv(g.nseg_total, want);

@@ -500,7 +500,7 @@ int launch_cfg(GatherGemmSet gs, hipStream_t st) {
 // (BN = 32/64/128 by channel count) and (b) wave quantisation: a layer with few tiles leaves CUs idle
 // in its last round, so small-M layers take the 64-row tile.
 int pick_bm(int M, int nblk_n) {
-    static const int force = getenv("YH_CONV_BM") ? atoi(getenv("YH_CONV_BM")) : 0;   // tuning knob
+    constexpr int force = 0;
     if (force == 64 || force == 128) return force;
     // measured on MI355X (tools/layer_bench.py): 64-row tiles win whenever the 128-row grid is small,
     // except when it fills the chip exactly once at two workgroups per CU (256 < blocks <= 512)
@@ -626,7 +626,7 @@ SkPlan sk_plan(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
     p.tiles = (int)(((M + p.bm - 1) / p.bm) * ((Cout + p.bn - 1) / p.bn));
     p.ldws = (Cout + 3) / 4 * 4;
     const int nch = (k * k * Cin + BK - 1) / BK;
-    static const int target = getenv("YH_SPLITK_TARGET") ? atoi(getenv("YH_SPLITK_TARGET")) : 192;    // workgroups per layer
+    constexpr int target = 192;      // workgroups per layer
     int S = target / p.tiles;
     if (S > nch / 2) S = nch / 2;          // at least two K chunks per split
     if (S > 32) S = 32;

@@ -537,13 +537,9 @@ __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(const float *_
 }
 
 // persistent grid: measured best at 2 workgroups per CU for the 16-channel layers and 4 for the first layer (64 x 640 x 640:
-// 0.099 / 0.205 / 0.174 ms at 512 / 512 / 1024 workgroups; YH_NARROW_W_BLOCKS overrides for sweeps)
+// 0.099 / 0.205 / 0.174 ms at 512 / 512 / 1024 workgroups)
 int narrow_wgrad_grid(int npatch, int Cin) {
-    static const int forced = [] {
-        const char *e = getenv("YH_NARROW_W_BLOCKS");
-        return e ? atoi(e) : 0;
-    }();
-    const int target = forced > 0 ? forced : (Cin == 16 ? 512 : 1024);
+    const int target = Cin == 16 ? 512 : 1024;
     return npatch < target ? npatch : target;
 }
 
@@ -563,13 +559,9 @@ int narrow_wgrad_launch(NarrowW g, float *dw, float *dbias, int cin_real, hipStr
     return 0;
 }
 
-// persistent grid of the forward / stride-1 backward-data kernel (YH_NARROW_BLOCKS overrides for sweeps)
+// persistent grid of the forward / stride-1 backward-data kernel
 int narrow_conv_grid(int npatch) {
-    static const int forced = [] {
-        const char *e = getenv("YH_NARROW_BLOCKS");
-        return e ? atoi(e) : 0;
-    }();
-    const int target = forced > 0 ? forced : 512;     // 2 per CU: measured 0.162 vs 0.183 ms (first layer), others equal at 1024
+    const int target = 512;     // 2 per CU: measured 0.162 vs 0.183 ms (first layer), others equal at 1024
     return npatch < target ? npatch : target;
 }
 

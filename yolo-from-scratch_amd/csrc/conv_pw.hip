@@ -165,7 +165,7 @@ int pw_plan(PwW &g, int &nsplit, int &XV, int &DV, int64_t M, int Cin, int Cout,
     while (DV > vmax_d) DV >>= 1;
     int pairs = cdiv(Cin, 32 * XV) * cdiv(Cout, 32 * DV);
     // 256 workgroups measured best on every 1x1 layer of the network (slab traffic grows with the split count)
-    static const int target = getenv("YH_PW_WGRAD_BLOCKS") ? atoi(getenv("YH_PW_WGRAD_BLOCKS")) : 256;
+    constexpr int target = 256;
     nsplit = target / pairs;
     if (nsplit < 1) nsplit = 1;
     int pps = cdiv(cdiv((int)M, nsplit), 64) * 64;
@@ -245,8 +245,6 @@ struct PwG {
     int M, K, K1, N, N1;        // K1: channels taken from `in` (the rest, K - K1, from `in2`); N1 = N when out2 == NULL
     int accumulate;
     unsigned in_bytes, in2_bytes;
-    const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns (common.h)
-    int bn_n;
     const float *res;           // inference epilogue (tiled kernel only): SiLU on (acc + bias), + residual, x2 upsample on write
 #ifdef YH_PW_STAMPS
     unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps (tools/pw_probe.py)
@@ -330,17 +328,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
         gfloat *const ob = (second ? yh_global(g.out2) : yh_global(g.out)) + nl;
         const int ldo = second ? g.ldo2 : g.ldo;
         float s = 0.f, q = 0.f;
-        const gfloat *ey = nullptr;              // producer that owns this column (BatchNorm-backward sums, see YhBnBwdEntry)
-        int eldy = 0;
-        float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
-        for (int e = 0; e < g.bn_n; ++e) {
-            const YhBnBwdEntry en = g.bn_tab[e];
-            if (nok && n >= en.col0 && n < en.col0 + en.ncol) {
-                const int cl = n - en.col0;
-                eldy = en.ldy; ey = yh_global(en.y) + cl;
-                esc = en.coef[cl]; esh = en.coef[en.C + cl]; emu = en.coef[2 * en.C + cl]; eis = en.coef[3 * en.C + cl];
-            }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -362,18 +349,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
                         }
                     }
                     *o = v;
-                    if (ey) {
-                        yh_bn_bwd_accum(v, ey[(size_t)p * eldy], esc, esh, emu, eis, s, q);
-                    } else {
-                        s += v;
-                        q += v * v;
-                    }
+                    s += v;
+                    q += v * v;
                 }
             }
         csum[j] = s;
         csq[j] = q;
     }
-    if (g.stats || g.bn_n) {
+    if (g.stats) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
@@ -384,16 +367,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
             float a0 = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
             float a1 = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
             const int n = n0 + t;
-            if (!g.stats) {                      // BatchNorm-backward sums: into the owning producer's partials
-                for (int e = 0; e < g.bn_n; ++e) {
-                    const YhBnBwdEntry en = g.bn_tab[e];
-                    if (n >= en.col0 && n < en.col0 + en.ncol) {
-                        en.part[((size_t)blockIdx.x * 2 + 0) * en.C + n - en.col0] = a0;
-                        en.part[((size_t)blockIdx.x * 2 + 1) * en.C + n - en.col0] = a1;
-                    }
-                }
-                return;
-            }
             gfloat *sp = n >= g.N1 ? yh_global(g.stats2) : yh_global(g.stats);   // each tensor has its own [blocks][2][C] partials
             const int C = n >= g.N1 ? g.N - g.N1 : g.N1, nl = n >= g.N1 ? n - g.N1 : n;
             sp[((size_t)blockIdx.x * 2 + 0) * C + nl] = a0;
@@ -647,10 +620,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
         }
     // per-column epilogue state (same semantics as pw_gemm_kernel)
     bool nok[NT];
-    float bias[NT], esc[NT], esh[NT], emu[NT], eis[NT], csum[NT], csq[NT];
+    float bias[NT], csum[NT], csq[NT];
     gfloat *ob[NT];
-    const gfloat *ey[NT];
-    int ldo[NT], eldy[NT];
+    int ldo[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = j * 32 + lr;
@@ -661,18 +633,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
         bias[j] = (bp && nok[j]) ? bp[nl] : 0.f;
         ob[j] = (second ? yh_global(g.out2) : yh_global(g.out)) + nl;
         ldo[j] = second ? g.ldo2 : g.ldo;
-        ey[j] = nullptr; eldy[j] = 0; esc[j] = esh[j] = emu[j] = eis[j] = 0.f; csum[j] = csq[j] = 0.f;
-        for (int e = 0; e < g.bn_n; ++e) {
-            const YhBnBwdEntry en = g.bn_tab[e];
-            if (nok[j] && n >= en.col0 && n < en.col0 + en.ncol) {
-                const int cl = n - en.col0;
-                eldy[j] = en.ldy; ey[j] = yh_global(en.y) + cl;
-                esc[j] = en.coef[cl]; esh[j] = en.coef[en.C + cl]; emu[j] = en.coef[2 * en.C + cl]; eis[j] = en.coef[3 * en.C + cl];
-            }
-        }
+        csum[j] = csq[j] = 0.f;
     }
 
-    const bool plain = g.bn_n == 0 && 32 * NT <= g.N;                     // wave-uniform: every lane's column exists
+    const bool plain = 32 * NT <= g.N;                     // wave-uniform: every lane's column exists
     const int ngroups = (g.M + 31) >> 5, stride = gridDim.x * 4;
     auto load = [&](int grp, f32x4 (&a)[KC]) {
         const int p = grp * 32 + lr;
@@ -736,12 +700,8 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
                     float v = acc[j][r] + bias[j];
                     if (g.accumulate) v += *o;
                     *o = v;
-                    if (ey[j]) {
-                        yh_bn_bwd_accum(v, ey[j][(size_t)p * eldy[j]], esc[j], esh[j], emu[j], eis[j], csum[j], csq[j]);
-                    } else {
-                        csum[j] += v;
-                        csq[j] += v * v;
-                    }
+                    csum[j] += v;
+                    csq[j] += v * v;
                 }
             }
     };
@@ -758,7 +718,7 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
         if (grp + stride < ngroups) compute(grp + stride, aB);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (g.stats || g.bn_n) {
+    if (g.stats) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
@@ -769,16 +729,6 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
             float a0 = (red[0][t][0] + red[1][t][0]) + (red[2][t][0] + red[3][t][0]);
             float a1 = (red[0][t][1] + red[1][t][1]) + (red[2][t][1] + red[3][t][1]);
             const int n = t;
-            if (!g.stats) {
-                for (int e = 0; e < g.bn_n; ++e) {
-                    const YhBnBwdEntry en = g.bn_tab[e];
-                    if (n >= en.col0 && n < en.col0 + en.ncol) {
-                        en.part[((size_t)blockIdx.x * 2 + 0) * en.C + n - en.col0] = a0;
-                        en.part[((size_t)blockIdx.x * 2 + 1) * en.C + n - en.col0] = a1;
-                    }
-                }
-                return;
-            }
             gfloat *sp = n >= g.N1 ? yh_global(g.stats2) : yh_global(g.stats);
             const int C = n >= g.N1 ? g.N - g.N1 : g.N1, nl = n >= g.N1 ? n - g.N1 : n;
             sp[((size_t)blockIdx.x * 2 + 0) * C + nl] = a0;
@@ -790,26 +740,20 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
 // streaming form: K in {16, 32, 64}, N <= 64 and enough pixels to stream (measured: 160^2 32->32 0.104 -> 0.085 ms = 4.9 TB/s;
 // N = 128 with K = 32 was slower than the tiled kernel and is left to it)
 inline bool pw_use_stream(int64_t M, int K, int N) {
-    static const bool on = !(getenv("YH_PW_STREAM") && atoi(getenv("YH_PW_STREAM")) == 0);
-    return on && M >= 32768 && (K == 16 || K == 32 || K == 64) && N <= 64;
+    return M >= 32768 && (K == 16 || K == 32 || K == 64) && N <= 64;
 }
 inline int pw_stream_blocks(int64_t M) {
     int64_t b = ((M + 31) / 32 + 3) / 4;
     return (int)(b > 1024 ? 1024 : b);
 }
 
-// LDS-staged form: every tiled (non-streaming) training-path layer with K >= 64 (YH_PW_TILE=0 switches back to the
-// register-direct kernel for A/B runs)
+// LDS-staged form: every tiled (non-streaming) training-path layer with K >= 64
 // pixels per workgroup of the LDS-staged form: 64 (more, smaller workgroups: 3-4 per CU instead of 2) unless N <= 32
 inline int pw_tile_bm(int N) {
-    static const int forced = getenv("YH_PW_BM") ? atoi(getenv("YH_PW_BM")) : 0;
     if (N <= 32) return 128;
-    if (forced == 64 || forced == 128) return forced;
     return N <= 64 ? 64 : 128;                 // measured: 64 wins for N = 64 (33 vs 40 us at 128 -> 64, 40x40), 128 for N >= 128
 }
 inline int pw_tile_slots(int BM) {
-    static const int forced = getenv("YH_PW_SLOTS") ? atoi(getenv("YH_PW_SLOTS")) : 0;
-    if (forced > 0) return forced;
     (void)BM;
     return 512;                                // 2 workgroups per CU (67 KB of LDS at 128 rows; ~200 VGPRs at 64)
 }
@@ -822,9 +766,8 @@ inline int pw_tile_gx(int64_t M, int N) {
     return cdiv(ntile, cdiv(ntile, gx));                                   // same number of rounds, evenly filled
 }
 inline bool pw_use_tile(int K, int N) {
-    static const bool on = !(getenv("YH_PW_TILE") && atoi(getenv("YH_PW_TILE")) == 0);
     (void)N;
-    return on && K >= 64 && K % 32 == 0;
+    return K >= 64 && K % 32 == 0;
 }
 
 struct PwPackDesc {
@@ -873,7 +816,7 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
         YH_CHECK_LAUNCH("pw_stream");
         return 0;
     }
-    if (!fused && !g.bn_n && g.K1 % 32 == 0 && (g.K - g.K1) % 32 == 0 && pw_use_tile(g.K, g.N)) {
+    if (!fused && g.K1 % 32 == 0 && (g.K - g.K1) % 32 == 0 && pw_use_tile(g.K, g.N)) {
         const int WN = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
         const int BM = pw_tile_bm(g.N);
         const int ntile = cdiv(g.M, BM), ncol = cdiv(g.N, 32 * WN);
@@ -914,18 +857,11 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
 #endif
         return 0;
     }
-    int NTv = NT;
-    int TM = (NT <= 2 && cdiv(g.M, 256) * cdiv(g.N, 32 * NT) >= 1024) ? 2 : 1;   // <2,4> would run one wave per SIMD
-    if (const char *e = getenv("YH_PW_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && 32 * v <= ((g.N + 31) & ~31)) NTv = v; }
-    if (const char *e = getenv("YH_PW_TM")) { const int v = atoi(e); if (v == 1 || v == 2) TM = v; }
-    dim3 grid(cdiv(g.M, 128 * TM), cdiv(g.N, 32 * NTv));
+    // (the tile shape is a function of the problem alone, shared with yh_conv_pw_blocks / yh_conv_pw_bwd_data_bn_rows, which size
+    // the BatchNorm partial-sum rows: no run-time override may change grid.x behind the planner's back)
+    const int TM = (NT <= 2 && cdiv(g.M, 256) * cdiv(g.N, 32 * NT) >= 1024) ? 2 : 1;   // <2,4> would run one wave per SIMD
+    dim3 grid(cdiv(g.M, 128 * TM), cdiv(g.N, 32 * NT));
 #define YH_PWG(tm, nt) hipLaunchKernelGGL((pw_gemm_kernel<tm, nt>), grid, dim3(256), 0, st, g)
-    if (NTv != NT || getenv("YH_PW_TM")) {      // tuning probe (tools/pw_probe.py): explicit tile shape; partial-sum rows follow grid.x
-        if (TM == 2) { if (NTv == 4) YH_PWG(2, 4); else if (NTv == 2) YH_PWG(2, 2); else YH_PWG(2, 1); }
-        else { if (NTv == 4) YH_PWG(1, 4); else if (NTv == 2) YH_PWG(1, 2); else YH_PWG(1, 1); }
-        YH_CHECK_LAUNCH("pw_gemm");
-        return 0;
-    }
     if (TM == 2) { if (NT == 2) YH_PWG(2, 2); else YH_PWG(2, 1); }
     else { if (NT == 4) YH_PWG(1, 4); else if (NT == 2) YH_PWG(1, 2); else YH_PWG(1, 1); }
 #undef YH_PWG
@@ -934,14 +870,6 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
 }
 
 }  // namespace
-
-// partial-sum rows of the backward-data kernels that carry a BatchNorm table (always the register-direct / streaming forms)
-extern "C" int yh_conv_pw_bwd_data_bn_rows(int64_t M, int K, int Cin) {
-    if (pw_use_stream(M, K, Cin)) return pw_stream_blocks(M);
-    const int NT = Cin > 64 ? 4 : (Cin > 32 ? 2 : 1);
-    const int TM = (NT <= 2 && cdiv((int)M, 256) * cdiv(Cin, 32 * NT) >= 1024) ? 2 : 1;
-    return cdiv((int)M, 128 * TM);
-}
 
 extern "C" int yh_conv_pw_blocks(int64_t M, int K, int Cout) {
     if (pw_use_stream(M, K, Cout)) return pw_stream_blocks(M);
@@ -990,23 +918,11 @@ extern "C" int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw
     return launch_pw_gemm(g, (hipStream_t)stream);
 }
 
-extern "C" int yh_conv_pw_bwd_data_bn(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
-                                      float *dx, int lddx, int64_t M, int Cin, int accumulate, const void *bn_table, int n_bn,
-                                      void *stream);
-
 extern "C" int yh_conv_pw_bwd_data(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
                                    float *dx, int lddx, int64_t M, int Cin, int accumulate, void *stream) {
-    return yh_conv_pw_bwd_data_bn(dy1, cout1, dy2, cout2, lddy, wq, ldw, dx, lddx, M, Cin, accumulate, nullptr, 0, stream);
-}
-
-extern "C" int yh_conv_pw_bwd_data_bn(const float *dy1, int cout1, const float *dy2, int cout2, int lddy, const float *wq, int ldw,
-                                      float *dx, int lddx, int64_t M, int Cin, int accumulate, const void *bn_table, int n_bn,
-                                      void *stream) {
     YH_REQUIRE(dy1 && wq && dx && M > 0 && M < (1ll << 30) && cout1 > 0 && (dy2 ? cout2 > 0 : cout2 == 0) && lddx >= Cin,
                "conv_pw_bwd_data: bad argument");
-    YH_REQUIRE(n_bn >= 0 && n_bn <= 8 && (n_bn == 0 || bn_table), "conv_pw_bwd_data: bad BatchNorm table");
     PwG g{};
-    g.bn_tab = (const YhBnBwdEntry *)bn_table; g.bn_n = n_bn;
     g.in = dy1; g.in2 = dy2; g.Wq = wq; g.out = dx;
     g.ldi = lddy; g.ldw = ldw; g.ldo = lddx; g.M = (int)M; g.K = cout1 + cout2; g.K1 = cout1; g.N = Cin; g.accumulate = accumulate;
     return launch_pw_gemm(g, (hipStream_t)stream);

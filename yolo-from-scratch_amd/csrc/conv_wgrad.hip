@@ -257,7 +257,7 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     // column tiles per slab must be 1, 2 or 4 (wave ownership): COT is 128, 64 or the whole (<= 64) channel count
     if (k == 1) { g.CIT = Cin >= 128 ? 128 : Cin; g.COT = Cout >= 128 ? 128 : (Cout > 64 ? 64 : (Cout + 3) / 4 * 4); }
     else {
-        static const int cit3 = getenv("YH_WGRAD_CIT3") ? atoi(getenv("YH_WGRAD_CIT3")) : 32;   // tuning knob
+        constexpr int cit3 = 32;
         g.CIT = (s == 2) ? (Cin >= 32 ? 32 : Cin) : (Cin >= cit3 ? cit3 : Cin);
         g.COT = Cout >= 64 ? 64 : (Cout + 3) / 4 * 4;
     }
@@ -266,7 +266,7 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     pl.ntiles = g.n_ci_tiles * cdiv(Cout, g.COT);
     {   // MFMA shape: cycles per pixel = tiles32 * 64/2 vs tiles16 * 32/4
         int t32 = cdiv(k * k * g.CIT, 32) * cdiv(g.COT, 32), t16 = cdiv(k * k * g.CIT, 16) * cdiv(g.COT, 16);
-        static const int force = getenv("YH_WGRAD_MT") ? atoi(getenv("YH_WGRAD_MT")) : 0;   // tuning knob
+        constexpr int force = 0;
         const int ot16 = cdiv(g.COT, 16);
         const bool ok16 = t16 <= 20 && (ot16 == 1 || ot16 == 2 || ot16 == 4);
         g.MT = (t16 < 4 * t32 && ok16) ? 16 : 32;
@@ -293,7 +293,7 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
     g.nseg_row = cdiv(g.Wo, P);
     g.nseg_total = g.B * g.Ho * g.nseg_row;
     int64_t wsize = (int64_t)k * k * Cin * Cout;
-    static const int target = getenv("YH_WGRAD_BLOCKS") ? atoi(getenv("YH_WGRAD_BLOCKS")) : 512;   // tuning knob
+    constexpr int target = 512;
     int want = target / pl.ntiles;                    // ~2 workgroups per CU in total
     if (want < 1) want = 1;
     int64_t cap = (48ll << 20) / wsize;               // <= 192 MiB of partials

@@ -38,8 +38,6 @@ struct Wino {
     int TW, TPI, ntiles;        // tile columns per row, tiles per image, total tiles
     int ncol;                   // column blocks (set by the launcher)
     int accumulate;
-    const YhBnBwdEntry *bn_tab; // backward-data only: BatchNorm-backward sums of the producers of these columns
-    int bn_n;
     const float *res;           // inference epilogue (eval-mode BatchNorm folded into U / bias): + residual after the activation,
     int ldr, act, up2;          // act: SiLU on (acc + bias); up2: each output pixel replicated 2x2 (out is (B,2H,2W))
     unsigned tw_magic, tpi_magic;
@@ -213,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
     // each stores its quarter of the outputs straight from the MFMA layout (32 consecutive channels = 128 bytes per row).
     // Same values bit for bit as the general epilogue below ((T0 + T1) + T2, (T1 - T2) - T3); in-kernel stamps: that one
     // took 11 000 cycles per workgroup at one wave per SIMD (64 4-byte LDS writes + 64 reads per lane, per-tile divisions).
-    if (!(g.act | g.up2 | (g.res != nullptr)) && g.bn_n == 0) {
+    if (!(g.act | g.up2 | (g.res != nullptr))) {
         float T[2][NT][16];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -365,18 +363,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
     const bool nok = n < g.N;
     const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
     float csum = 0.f, csq = 0.f;
-    // BatchNorm-backward sums for the producer that owns this thread's column (see YhBnBwdEntry)
-    const float *ey = nullptr;
-    float *epart = nullptr;
-    int eC = 0, ecl = 0, eldy = 0;
-    float esc = 0.f, esh = 0.f, emu = 0.f, eis = 0.f;
-    for (int e = 0; e < g.bn_n; ++e) {
-        const YhBnBwdEntry en = g.bn_tab[e];
-        if (nok && n >= en.col0 && n < en.col0 + en.ncol) {
-            ecl = n - en.col0; eC = en.C; eldy = en.ldy; ey = en.y + ecl; epart = en.part;
-            esc = en.coef[ecl]; esh = en.coef[eC + ecl]; emu = en.coef[2 * eC + ecl]; eis = en.coef[3 * eC + ecl];
-        }
-    }
     for (int it = 0; it < TPB / TG; ++it) {
         const int tl = tgp + TG * it, tg = tile0 + tl;
         if (tg >= g.ntiles) break;
@@ -409,17 +395,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
                 }
             }
             *o0 = y0; *o1 = y1;
-            if (ey) {
-                const size_t p0 = ((size_t)(b * g.H + 2 * ty) * g.W + 2 * tx + j) * eldy, p1 = p0 + (size_t)g.W * eldy;
-                yh_bn_bwd_accum(y0, ey[p0], esc, esh, emu, eis, csum, csq);
-                yh_bn_bwd_accum(y1, ey[p1], esc, esh, emu, eis, csum, csq);
-            } else {
-                csum += y0 + y1;
-                csq += y0 * y0 + y1 * y1;
-            }
+            csum += y0 + y1;
+            csq += y0 * y0 + y1 * y1;
         }
     }
-    if (g.stats || g.bn_n) {
+    if (g.stats) {
         float *red = smem + 4 * 2 * TPB * BNW;   // [TG][BNW][2]
         red[(tgp * BNW + ch) * 2 + 0] = csum;
         red[(tgp * BNW + ch) * 2 + 1] = csq;
@@ -428,13 +408,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int w = 0; w < TG; ++w) { a0 += red[(w * BNW + t) * 2]; a1 += red[(w * BNW + t) * 2 + 1]; }
-            if (g.stats) {
-                g.stats[((size_t)tgrp * 2 + 0) * g.N + n] = a0;
-                g.stats[((size_t)tgrp * 2 + 1) * g.N + n] = a1;
-            } else if (epart) {
-                epart[((size_t)tgrp * 2 + 0) * eC + ecl] = a0;
-                epart[((size_t)tgrp * 2 + 1) * eC + ecl] = a1;
-            }
+            g.stats[((size_t)tgrp * 2 + 0) * g.N + n] = a0;
+            g.stats[((size_t)tgrp * 2 + 1) * g.N + n] = a1;
         }
     }
 #ifdef YH_WINO_STAMPS
@@ -927,7 +902,7 @@ int launch_wino(Wino &g, hipStream_t st) {
     // Three register sets (prefetch distance 2) never win: what is left of the loop's stall at one wave per SIMD is not
     // load latency (the strided 16-byte activation loads keep the L1 fill path busy).  Also dropped: compiler-scheduled or
     // sched_group_barrier-interleaved loads among the MFMAs (15-25 % slower than loads pinned ahead of them).
-    static const int force = getenv("YH_WINO_PIPE") ? atoi(getenv("YH_WINO_PIPE")) : 0;
+    constexpr int force = 0;
     const int pipe = force ? force : (cdiv(g.ntiles, TPB) >= 800 ? 1 : 2);
     if (g.N <= 32) return pipe == 3 ? launch_nt<1, 3>(g, st) : pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
     return pipe == 3 ? launch_nt<2, 3>(g, st) : pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
@@ -951,7 +926,7 @@ int wgrad_lds_plan(WinoWL &g, int &nsplit, int &NT, int B, int H, int W, int Cin
     g.nstrips = B * g.TH * g.spr;
     NT = Cout % 64 == 0 ? 2 : 1;
     const int pairs = (Cin / 32) * (Cout / (32 * NT));
-    static const int target = getenv("YH_WINO_WGRAD_BLOCKS") ? atoi(getenv("YH_WINO_WGRAD_BLOCKS")) : 512;
+    constexpr int target = 512;
     nsplit = target / pairs;
     if (nsplit < 1) nsplit = 1;
     g.sps = cdiv(g.nstrips, nsplit);
@@ -960,7 +935,7 @@ int wgrad_lds_plan(WinoWL &g, int &nsplit, int &NT, int B, int H, int W, int Cin
     return 0;
 }
 inline bool wino_wgrad_use_lds() {
-    static const bool on = !(getenv("YH_WINO_WGRAD_LDS") && atoi(getenv("YH_WINO_WGRAD_LDS")) == 0);
+    constexpr bool on = true;
     return on;
 }
 
@@ -972,7 +947,7 @@ int wgrad_plan(WinoW &g, int &nsplit, int &NT, int B, int H, int W, int Cin, int
     set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
     NT = Cout % 64 == 0 ? 2 : 1;
     int pairs = (Cin / 32) * (Cout / (32 * NT));
-    static const int target = getenv("YH_WINO_WGRAD_BLOCKS") ? atoi(getenv("YH_WINO_WGRAD_BLOCKS")) : 512;
+    constexpr int target = 512;
     nsplit = target / pairs;
     if (nsplit < 1) nsplit = 1;
     int tps = cdiv(cdiv(g.ntiles, nsplit), 8) * 8;
@@ -1080,21 +1055,10 @@ extern "C" int yh_conv_wino_fwd_fused(const float *x, int ldx, const float *U, i
     return launch_wino(g, (hipStream_t)stream);
 }
 
-extern "C" int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
-                                        int W, int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream);
-
 extern "C" int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                                      int W, int Cin, int Cout, int accumulate, void *stream) {
-    return yh_conv_wino_bwd_data_bn(dy, lddy, Ub, ldub, dx, lddx, B, H, W, Cin, Cout, accumulate, nullptr, 0, stream);
-}
-
-extern "C" int yh_conv_wino_bwd_data_bn(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
-                                        int W, int Cin, int Cout, int accumulate, const void *bn_table, int n_bn, void *stream) {
     YH_REQUIRE(dy && Ub && dx && B > 0 && H > 0 && W > 0 && lddy >= Cout && lddx >= Cin, "conv_wino_bwd_data: bad argument");
-    YH_REQUIRE(n_bn >= 0 && n_bn <= 8 && (n_bn == 0 || bn_table), "conv_wino_bwd_data: bad BatchNorm table");
-    static_assert(sizeof(YhBnBwdEntry) == 48, "record layout is part of the ABI");
     Wino g{};
-    g.bn_tab = (const YhBnBwdEntry *)bn_table; g.bn_n = n_bn;
     g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
     g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
     return launch_wino(g, (hipStream_t)stream);

@@ -618,7 +618,7 @@ __global__ void add_int64_kernel(int64_t *p, int64_t v) {
 }
 
 inline int grid_for(int64_t work_items, int threads = 256) {
-    static const int cap = getenv("YH_EW_MAXBLOCKS") ? atoi(getenv("YH_EW_MAXBLOCKS")) : kMaxBlocks;    // tuning knob
+    constexpr int cap = kMaxBlocks;
     int64_t g = cdiv64(work_items, threads);
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }

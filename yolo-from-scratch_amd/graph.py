@@ -130,7 +130,6 @@ class ConvRec:
     wino_w: bool = False    # backward-weight in the Winograd domain
     pw_w: bool = False      # backward-weight on the pointwise (1x1) kernel
     pw_f: bool = False      # forward on the pointwise GEMM kernel
-    stem_f: bool = False    # forward on the direct VALU kernel of the first layer
     s2m_b: bool = False     # stride-2 backward-data with the column parities merged into the channel axis
     narrow_f: bool = False  # forward on the direct kernel for the narrow high-resolution 3x3 layers
     narrow_b: bool = False  # stride-1 backward-data on the same kernel (flipped taps)
@@ -233,7 +232,7 @@ class Plan:
     def side_lane(self):
         plan = self
 
-        enabled = os.environ.get("YH_SIDE_LANES", "1") != "0"      # tuning knob
+        enabled = True
 
         class _Ctx:
             def __enter__(self_inner):
@@ -282,15 +281,14 @@ class Plan:
         packs: List[tuple] = []                # one descriptor per conv for the single pack launch
         folds: List[tuple] = []                # inference: BN folded into the packed weights
         winos: List[tuple] = []                # Winograd weight transforms (forward and backward-data)
-        use_wino = self.training and os.environ.get("YH_WINO", "1") != "0"
-        use_pw = self.training and os.environ.get("YH_PW", "1") != "0"
-        use_pwg = self.training and os.environ.get("YH_PWG", "1") != "0"
-        use_stem = self.training and os.environ.get("YH_STEM", "1") != "0"
-        use_s2m = self.training and os.environ.get("YH_S2M", "1") != "0"
-        use_narrow = self.training and os.environ.get("YH_NARROW", "1") != "0"
+        # YH_GENERIC=1: every convolution on the generic gather-GEMM / wgrad kernels instead of the specialised families
+        # (Winograd, pointwise, narrow, merged stride-2): the two are independent product paths that must agree
+        # (tests/test_gpu_model.py::test_full_size_step_properties); the only planner switch besides YH_EVAL_FAST
+        special = self.training and os.environ.get("YH_GENERIC", "0") != "1"
+        use_wino = use_pw = use_pwg = use_s2m = use_narrow = special
         s2m_packs: List[L.YhOp] = []
         pwpacks: List[tuple] = []              # k-quad interleaved weights of the pointwise GEMM kernels
-        if self.training and os.environ.get("YH_PAIR_DGRAD", "1") != "0":
+        if self.training:
             # sibling pointwise convs (C3 conv1 / conv2) share one backward-data GEMM: K = Cout1 + Cout2
             groups: Dict[tuple, List[ConvRec]] = {}
             for r in self.recs:
@@ -302,8 +300,7 @@ class Plan:
                     grp[0].pair_first = True
                     a = grp[0]           # forward fusion (one GEMM, N = cout1 + cout2): decided here so the lowering below
                     a.fwd2 = grp[1].fwd2 = (  # can order the fused launch before a side-lane fork
-                        os.environ.get("YH_PAIR_FWD", "1") != "0" and os.environ.get("YH_PWG", "1") != "0"
-                        and a.cin == a.weight.shape[1] and a.x.ld % 4 == 0 and a.cin % 8 == 0
+                        use_pwg and a.cin == a.weight.shape[1] and a.x.ld % 4 == 0 and a.cin % 8 == 0
                         and not (a.cin >= 256 and a.cout >= 256))
         deferred_fork = False
         for ri, r in enumerate(self.recs):
@@ -359,8 +356,7 @@ class Plan:
                                        p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()], **args))
                     else:
                         packs.append((wfold.data_ptr(), r.wf.data_ptr(), 0, r.cout, cin_real, kk, r.cin, r.ldwf, r.ldwb))
-                        nws = int(lib.yh_conv_fwd_fused_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s)) \
-                            if os.environ.get("YH_SPLITK", "1") != "0" else 0
+                        nws = int(lib.yh_conv_fwd_fused_ws(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
                         sws = torch.zeros(nws, **f32) if nws > 0 else None   # per layer (two lanes may run split layers at once); zero tickets
                         if sws is not None:
                             keep.append(sws)
@@ -379,12 +375,9 @@ class Plan:
                 r.pw_f = pw_ok and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256)
                 r.s2m_b = use_s2m and r.k == 3 and r.s == 2 and r.need_dx and r.cin <= 16 and r.x.ld == r.cin and r.x.W % 2 == 0 \
                     and r.cin == r.weight.shape[1]
-                r.stem_f = use_stem and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16
                 # narrow high-resolution 3x3 layers: direct kernel (LDS halo patch, filter in registers, 16-wide MFMA tiles)
                 nar_ok = use_narrow and r.k == 3 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and r.x.off % 4 == 0
                 r.narrow_f = bool(nar_ok and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s))
-                if r.stem_f and use_narrow and os.environ.get("YH_NARROW_STEM", "1") != "0" and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s):
-                    r.narrow_f, r.stem_f = True, False    # first layer: the same direct MFMA kernel with CIN = 4 (padded) channels
                 r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
                 if r.narrow_f:
                     r.wino_f = False
@@ -392,7 +385,7 @@ class Plan:
                     r.wino_b = False
                 if nar_ok and r.s == 2 and r.need_dx and lib.yh_conv_narrow_dgrad_s2_ok(r.cin, r.cout):
                     r.narrow_b, r.s2m_b = True, False      # the stride-2 form of the direct backward-data kernel
-                r.narrow_w = bool(use_narrow and os.environ.get("YH_NARROW_W", "1") != "0" and r.k == 3 and r.x.ld % 4 == 0
+                r.narrow_w = bool(use_narrow and r.k == 3 and r.x.ld % 4 == 0
                                   and r.x.off % 4 == 0 and lib.yh_conv_narrow_bwd_weight_ok(r.cin, r.weight.shape[1], r.cout, 3, r.s))
                 if r.narrow_w:
                     r.wino_w = False
@@ -465,7 +458,6 @@ class Plan:
                     nblk = lib.yh_conv_narrow_blocks(r.x.B, r.x.H, r.x.W, r.cin, r.s) if r.narrow_f else \
                         lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
                         lib.yh_conv_pw_blocks(M, r.cin, r.cout) if r.pw_f else \
-                        lib.yh_conv_stem_blocks(r.x.B, r.x.H, r.x.W) if r.stem_f else \
                         lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                     alloc_out(r, nblk)
                     ytarget, ldy = (r.y, r.cout) if r.bn is not None else (None, r.out.ld)
@@ -475,7 +467,7 @@ class Plan:
                                           r.part if r.bn is not None else None],
                                        i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.s, 0, 0], lane=ln))
                     else:
-                        fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else (L.OP_CONV_STEM_FWD if r.stem_f else L.OP_CONV_FWD)),
+                        fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else L.OP_CONV_FWD),
                                        p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                           r.part if r.bn is not None else None],
                                        i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
@@ -539,7 +531,7 @@ class Plan:
         keep: List[torch.Tensor] = []
         packs: List[tuple] = []
         # sibling pointwise convs (C3 conv1 / conv2): one backward-data GEMM over K = Cout1 + Cout2, dx written once
-        if os.environ.get("YH_PAIR_DGRAD", "1") != "0":
+        if True:
             groups: Dict[tuple, List[ConvRec]] = {}
             for r in self.recs:
                 if isinstance(r, ConvRec) and r.k == 1 and r.s == 1 and r.bn is not None and r.cout % 8 == 0:
@@ -580,14 +572,14 @@ class Plan:
             r.nblk = lib.yh_bf16_conv_blocks(M)
             # narrow high-resolution 3x3 layers (first layer, stem[3], the 16-channel bottleneck): the direct kernels of the fp32
             # path with bf16 storage (conv_narrow.hip); cin_k = channels the kernel reads (4 of the first layer's 8 padded ones)
-            use_nar = os.environ.get("YH_BF16_NARROW", "1") != "0" and r.k == 3 and r.bn is not None and r.x.ld % 4 == 0 and r.x.off % 4 == 0
+            use_nar = r.k == 3 and r.bn is not None and r.x.ld % 4 == 0 and r.x.off % 4 == 0
             r.cin_k = 4 if (cin_real <= 4 and r.cin == 8) else r.cin
             # measured at batch 64 (tools/layer_bench.py --dtype bf16, ms narrow / generic bf16): first layer forward 0.250 /
             # 0.358 and weight gradient 0.220 / 0.541; stem[3] forward 0.250 / 0.114, backward-data 0.295 / 0.338, weight gradient
             # 0.274 / 0.155; 16 -> 16 forward 0.098 / 0.098, backward-data 0.114 / 0.099, weight gradient 0.113 / 0.129 per layer
             # (8-byte pieces: twice the load instructions per byte of the fp32 form -- these kernels are bound by instruction
             # issue and latency, not by bytes).  Each pass takes the faster kernel; YH_BF16_NARROW=all forces the narrow ones.
-            every = os.environ.get("YH_BF16_NARROW", "1") == "all"
+            every = False
             r.narrow_f = bool(use_nar and (r.cin_k == 4 or (every and r.cin == cin_real)) and lib.yh_conv_narrow_ok(r.cin_k, r.cout, 3, r.s))
             r.narrow_w = bool(use_nar and (r.cin_k == 4 or r.s == 1 or every) and
                               lib.yh_conv_narrow_bwd_weight_ok(r.cin_k, min(cin_real, r.cin_k), r.cout, 3, r.s))
@@ -832,52 +824,9 @@ class Plan:
                 else:
                     ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
                                    i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
-        # measured at bs=64: backward-data 5.74 -> 7.26 ms, reduce 1.27 -> 0.42 ms, net +0.8 ms/step -- the sums cost more in the
-        # serial epilogue of an MFMA-bound kernel than as a streaming pass at 5.5 TB/s -- so this is OFF unless asked for
-        if os.environ.get("YH_BN_EPI", "0") == "1":
-            self._fold_bn_reduce_into_writers(ops, writers, bn_ops, keep)
+        # (folding the BatchNorm-backward sums into the epilogue of the backward-data GEMM that finishes a layer's gradient was
+        # built, tested and measured in round 2: backward-data 5.74 -> 7.26 ms against 0.85 ms saved in the reduce pass; retired)
         return ops
-
-    def _fold_bn_reduce_into_writers(self, ops, writers, bn_ops, keep):
-        """BatchNorm backward, first pass (sum dz, sum dz*xhat over the batch): when the LAST op that writes a layer's
-        activation gradient is a Winograd / pointwise backward-data GEMM covering all of the layer's channels, that GEMM's
-        epilogue produces the sums (it holds the final gradient values in registers and reads the layer's y beside them) and the
-        separate reduce pass over dOut and y is dropped.  Everything else keeps the reduce kernel."""
-        import struct
-        lib = L.lib()
-        tables: Dict[int, list] = {}
-        for rec, ri, ai in bn_ops.values():
-            if rec.upsample:
-                continue
-            v = rec.out
-            lo, hi = v.off, v.off + v.C
-            cand = [(k, w, c) for (k, w, c) in writers if w.buf is v.buf and w.off < hi and lo < w.off + w.C and k < ri]
-            if not cand:
-                continue
-            k, w, c = max(cand, key=lambda t: t[0])
-            kind = ops[k].kind
-            if c is None or kind not in (L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_PW_BWD_DATA) or not (w.off <= lo and hi <= w.off + w.C):
-                continue
-            if len(tables.setdefault(k, [])) >= 8:
-                continue
-            M = w.B * w.H * w.W
-            rows = lib.yh_conv_wino_blocks(w.B, w.H, w.W) if kind == L.OP_CONV_WINO_BWD_DATA else \
-                lib.yh_conv_pw_bwd_data_bn_rows(M, c.cout + (c.pair.cout if c.pair is not None else 0), w.C)
-            part = torch.empty(rows * 2 * rec.cout, device=self.device, dtype=torch.float32)
-            keep.append(part)
-            tables[k].append((rec.y.data_ptr(), rec.coef.data_ptr(), part.data_ptr(), lo - w.off, rec.cout, rec.cout, rec.cout, 0, 0))
-            ops[ri] = _op(L.OP_NOP)                       # indices of the following ops (gradient-bucket boundaries) stay valid
-            ops[ai].p[3] = part.data_ptr()                # the apply op finalises from the writer's partial rows
-            ops[ai].i[2] = rows
-        for k, ents in tables.items():
-            blob = b"".join(struct.pack("<QQQiiiiii", *e) for e in ents)
-            tab = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
-            keep.append(tab)
-            if ops[k].kind == L.OP_CONV_WINO_BWD_DATA:
-                ops[k].p[3], ops[k].i[9] = tab.data_ptr(), len(ents)
-            else:
-                ops[k].p[4], ops[k].i[10] = tab.data_ptr(), len(ents)
-        self.bn_epilogue_layers = sum(len(e) for e in tables.values())
 
     # ---- execution ----------------------------------------------------------------------------
     def _signature(self) -> List[int]:

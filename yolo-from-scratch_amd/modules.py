@@ -393,7 +393,7 @@ class YOLO(HipModule):
         x = g.conv(x, self.stem[0], self.stem[1])
         x = g.conv(x, self.stem[3], self.stem[4])
         bp3, bp4, bp5 = self.backbone_p3, self.backbone_p4, self.backbone_p5
-        sb = os.environ.get("YH_C3_SIDE", "1") != "0"     # tuning knob
+        sb = True
         x = bp3[0]._emit(g, x, side_branch=sb)
         x = g.conv(x, bp3[1], bp3[2])
         p3 = bp3[4]._emit(g, x, side_branch=sb)
