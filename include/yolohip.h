@@ -381,10 +381,22 @@ int yh_adam_step(float *p, float *g, float *m, float *v, int64_t n, double lr, d
  * destination may be NULL; rows / columns beyond the real channel counts are zero. */
 int yh_bf16_pack_multi(const void *table, int n, void *stream);
 /* y = conv(x, wf) (+ bias); y is bf16, or fp32 when y_f32 (head outputs feeding the fp32 loss).  bn_partials:
- * [yh_bf16_conv_blocks(M)][2][Cout] sums / sums of squares of the STORED (bf16-rounded) values, or NULL. */
+ * [yh_bf16_conv_fwd_blocks(B, Hi, Wi, Cin, Cout, k, s, y_f32, ldx, ldy)][2][Cout] sums / sums of squares of the STORED (bf16-rounded)
+ * values, or NULL.  Stride-1 layers with 16 / 32 / 64 / 128 input channels (3x3: up to 64) and bf16 output run as a flat
+ * pixel stream with ONE partial row per persistent workgroup (conv_bf16_stream.hip); the rest on the gather GEMM with one
+ * row per 128 output pixels (yh_bf16_conv_blocks(M)). */
 int yh_bf16_conv_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, int y_f32,
                      float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
 int yh_bf16_conv_blocks(int64_t M);
+/* The flat-stream kernels forced (tests, benchmarks; the dispatch above picks them where they measured faster): same contracts
+ * as yh_bf16_conv_fwd with bf16 output / yh_bf16_conv_bwd_data at stride 1.  yh_bf16_conv_stream_blocks: 0 when the kernel
+ * cannot run the problem (K streamed channels in {16, 32, 64, 128}, 3x3: K <= 64; N % 8 == 0), else its BatchNorm partial rows. */
+int yh_bf16_conv_stream_blocks(int B, int Hi, int Wi, int K, int N, int k);
+int yh_bf16_conv_stream_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, float *bn_partials,
+                            int B, int Hi, int Wi, int Cin, int Cout, int k, void *stream);
+int yh_bf16_conv_stream_bwd_data(const void *dy, int lddy, const void *dy2, int kcout1, const void *wb, int ldwb, void *dx, int lddx,
+                                 int B, int Hi, int Wi, int Cin, int Cout, int k, int accumulate, void *stream);
+int yh_bf16_conv_fwd_blocks(int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int y_f32, int ldx, int ldy);
 /* dx (+)= conv_transpose(dy, wb); Cout = K rows of wb (a multiple of 8: pad dY with zeros).  dy2 != NULL: pointwise
  * only, K rows [0, kcout1) come from dy, [kcout1, Cout) from dy2 (same ld): the fused C3 sibling pair. */
 int yh_bf16_conv_bwd_data(const void *dy, int lddy, const void *dy2, int kcout1, const void *wb, int ldwb, void *dx, int lddx,

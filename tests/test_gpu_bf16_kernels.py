@@ -97,7 +97,7 @@ def test_bf16_conv_fwd_dgrad_wgrad(case):
     xg = nhwc_bf16(x, cpad=cin, ld=cin + 8, off=8)          # a channel-slice view of a wider buffer
     xv = xg.view(-1)[8:]
     wf, ldf, wb, ldb = pack(L, w.cuda(), cin)
-    nblk = lib.yh_bf16_conv_blocks(B * Ho * Wo)
+    nblk = lib.yh_bf16_conv_fwd_blocks(B, H, W, cin, Cout, k, s, 1 if head else 0, cin + 8, Cout if head else Cout + 8)
     part = torch.zeros(nblk * 2 * Cout, device="cuda")
     bd = bias.cuda() if has_bias else None
     if head:
@@ -153,6 +153,68 @@ def test_bf16_conv_fwd_dgrad_wgrad(case):
     assert torch.equal(dw, dw2)                                               # deterministic
 
 
+STREAM_CASES = [  # (B, H, W, K, N, k): the flat-stream kernel forced (the dispatch only picks it where it measured faster)
+    (2, 20, 20, 16, 16, 3), (1, 40, 40, 32, 32, 3), (2, 12, 100, 16, 32, 3), (1, 16, 16, 64, 64, 3), (3, 9, 7, 64, 32, 3),
+    (2, 20, 20, 32, 16, 1), (2, 13, 11, 64, 24, 1), (1, 10, 10, 128, 128, 1), (1, 37, 5, 128, 64, 1), (2, 8, 8, 16, 128, 1),
+    (1, 30, 30, 64, 64, 1), (1, 200, 3, 32, 64, 3),
+]
+
+
+@pytest.mark.parametrize("B,H,W,K,N,k", STREAM_CASES)
+def test_bf16_flat_stream_fwd_and_bwd_data(B, H, W, K, N, k):
+    """yh_bf16_conv_stream_fwd / _bwd_data (conv_bf16_stream.hip) on every tile shape they instantiate: output, untouched
+    neighbouring channels of a view, BatchNorm partial rows (one per persistent workgroup, padding positions excluded),
+    backward-data plain / accumulating and with K split over two source tensors (the C3 sibling pair)."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(B * 1000 + H * 10 + K + N)
+    st = torch.cuda.current_stream().cuda_stream
+    p = k // 2
+    x = bf(torch.randn(B, K, H, W))
+    w = torch.randn(N, K, k, k) / (K * k * k) ** 0.5
+    wq = bf(w)
+    bias = torch.randn(N)
+    ref = F.conv2d(x.double(), wq.double(), bias.double(), 1, p)
+    xg = nhwc_bf16(x, cpad=K, ld=K + 8, off=8)
+    xv = xg.view(-1)[8:]
+    wf, ldf, wb, ldb = pack(L, w.cuda(), K)
+    nblk = lib.yh_bf16_conv_stream_blocks(B, H, W, K, N, k)
+    assert nblk > 0
+    part = torch.zeros(nblk * 2 * N, device="cuda")
+    ld = N + 8
+    ybuf = torch.full((B, H, W, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.yh_bf16_conv_stream_fwd(xv.data_ptr(), K + 8, wf.data_ptr(), ldf, bias.cuda().data_ptr(), ybuf.view(-1)[8:].data_ptr(), ld,
+                                        part.data_ptr(), B, H, W, K, N, k, st), "stream fwd")
+    y = ybuf[..., 8:].float().permute(0, 3, 1, 2)
+    assert rel_err(y, ref) < BF16_OUT_TOL
+    assert bool((ybuf[..., :8] == 7.0).all())
+    ps = part.view(nblk, 2, N).sum(0).cpu().double()
+    yd = y.double().cpu()
+    assert rel_err(ps[0], yd.sum((0, 2, 3))) < 1e-3
+    assert rel_err(ps[1], (yd * yd).sum((0, 2, 3))) < 1e-4
+    # backward-data of a conv whose OUTPUT channels are streamed (K of the GEMM) and whose input channels are produced (N)
+    if lib.yh_bf16_conv_stream_blocks(B, H, W, N, K, k) == 0 or N % 8:
+        return
+    dy = bf(torch.randn(B, N, H, W))
+    dyg = nhwc_bf16(dy, cpad=N)
+    want = F.conv_transpose2d(dy.double(), wq.double(), None, 1, p)
+    dxbuf = torch.full((B, H, W, K + 8), 5.0, dtype=torch.bfloat16, device="cuda")
+    dxv = dxbuf.view(-1)[8:]
+    for acc, mult in ((0, 1), (1, 2)):
+        L.check(lib.yh_bf16_conv_stream_bwd_data(dyg.data_ptr(), N, None, 0, wb.data_ptr(), ldb, dxv.data_ptr(), K + 8, B, H, W, K, N, k, acc,
+                                                 st), "stream bwd_data")
+        dx = dxbuf[..., 8:].float().permute(0, 3, 1, 2)
+        assert rel_err(dx, mult * want) < mult * BF16_OUT_TOL
+        assert bool((dxbuf[..., :8] == 5.0).all())
+    if k == 1 and N >= 32:      # the C3 sibling pair: dY of the two convs in two tensors, one stacked backward pack
+        n1 = N // 2
+        d1, d2 = nhwc_bf16(dy[:, :n1], cpad=n1), nhwc_bf16(dy[:, n1:], cpad=N - n1)
+        dx2 = torch.empty(B, H, W, K, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.yh_bf16_conv_stream_bwd_data(d1.data_ptr(), n1, d2.data_ptr(), n1, wb.data_ptr(), ldb, dx2.data_ptr(), K, B, H, W, K, N, k,
+                                                 0, st), "stream bwd_data pair")
+        assert rel_err(dx2.float().permute(0, 3, 1, 2), want) < BF16_OUT_TOL
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", [(2, 13, 11, 64, 24, 1, 1), (1, 17, 9, 32, 40, 3, 1), (2, 10, 14, 16, 16, 3, 2)])
 def test_bf16_conv_direct_store_variants(B, H, W, Cin, Cout, k, s):
     """Outputs whose row pitch is not a multiple of 8 elements cannot take the staged 16-byte stores: forward and
@@ -170,7 +232,7 @@ def test_bf16_conv_direct_store_variants(B, H, W, Cin, Cout, k, s):
     Ho, Wo = ref.shape[2], ref.shape[3]
     xg = nhwc_bf16(x)
     wf, ldf, wb, ldb = pack(L, w.cuda(), Cin)
-    nblk = lib.yh_bf16_conv_blocks(B * Ho * Wo)
+    nblk = lib.yh_bf16_conv_fwd_blocks(B, H, W, Cin, Cout, k, s, 0, Cin, Cout + 4)
     part = torch.zeros(nblk * 2 * Cout, device="cuda")
     ld = Cout + 4                                   # 8-byte aligned rows only
     ybuf = torch.full((B, Ho, Wo, ld), 7.0, dtype=torch.bfloat16, device="cuda")

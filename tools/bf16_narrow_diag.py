@@ -32,7 +32,7 @@ def main():
         y1 = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device="cuda")
         y2 = torch.empty_like(y1)
         n1 = lib.yh_conv_narrow_blocks(B, H, W, cin_k, s)
-        n2 = lib.yh_bf16_conv_blocks(B * Ho * Wo)
+        n2 = max(lib.yh_bf16_conv_blocks(B * Ho * Wo), 512)
         p1, p2 = torch.zeros(n1 * 2 * Cout, device="cuda"), torch.zeros(n2 * 2 * Cout, device="cuda")
         L.check(lib.yh_bf16_conv_narrow(x.data_ptr(), cin, wf.data_ptr(), ldf, cin, bias.data_ptr(), y1.data_ptr(), Cout, p1.data_ptr(),
                                         B, H, W, cin_k, Cout, s, 0, 0, st))

@@ -34,7 +34,7 @@ def main():
     tab = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
     L.check(lib.yh_bf16_pack_multi(tab.data_ptr(), 1, st), "pack")
     y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
-    part = torch.empty(lib.yh_bf16_conv_blocks(B * Ho * Wo) * 2 * Cout, device=dev)
+    part = torch.empty(max(lib.yh_bf16_conv_blocks(B * Ho * Wo), 512) * 2 * Cout, device=dev)
 
     dy = torch.randn(B, Ho, Wo, ldf, device=dev).to(torch.bfloat16)
     nws = int(lib.yh_bf16_conv_bwd_weight_ws(B, H, W, Cin, Cout, k, s))

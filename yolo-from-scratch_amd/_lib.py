@@ -107,6 +107,10 @@ _SIGS = {
     "yh_bf16_pack_multi": (i32, [c_fp, i32, c_fp]),
     "yh_bf16_conv_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_bf16_conv_blocks": (i32, [i64]),
+    "yh_bf16_conv_stream_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
+    "yh_bf16_conv_stream_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_stream_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_conv_fwd_blocks": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     "yh_bf16_conv_bwd_data": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_bf16_conv_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_bf16_conv_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32, i32, i32]),

@@ -28,3 +28,12 @@ bool yh_bf16_wgrad_stream_ok(int W, int Cin, int Cout, int k, int s);
 int64_t yh_bf16_wgrad_stream_ws(int B, int H, int W, int Cin, int Cout, int k);
 int yh_bf16_wgrad_stream(const void *x, int ldx, const void *dy, int lddy, float *ws, int64_t ws_floats, int B, int H, int W, int Cin,
                          int Cout, int k, int *nsplit, hipStream_t st);
+
+// Flat-stream forward / backward-data of the stride-1 layers (K = 16 / 32 / 64 / 128 streamed channels, bf16 output).
+// stats: [yh_bf16_fstream_blocks(...)][2][N] BatchNorm partial rows (ONE per persistent workgroup).
+bool yh_bf16_fstream_supported(int B, int H, int W, int K, int N, int k, int s);   // the kernel can run the problem
+bool yh_bf16_fstream_ok(int B, int H, int W, int K, int N, int k, int s);          // ... and measured faster than the gather GEMM
+int yh_bf16_fstream_blocks(int B, int H, int W, int K, int N, int k);
+int yh_bf16_fstream(const void *in, const void *in2, int ksplit, int ldi, const void *w, int ldw, const float *bias, void *out, int ldo,
+                    float *stats, int B, int H, int W, int K, int N, int k, int accumulate, const int *tap_dy, const int *tap_dx,
+                    const int *tap_w, hipStream_t st);

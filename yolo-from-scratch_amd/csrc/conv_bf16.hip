@@ -851,13 +851,73 @@ extern "C" int yh_bf16_pack_multi(const void *table, int n, void *stream) {
 
 extern "C" int yh_bf16_conv_blocks(int64_t M) { return (int)cdiv64(M, GEMM_BM); }
 
+// which kernel yh_bf16_conv_fwd runs for a problem -- and therefore how many BatchNorm partial rows it writes
+static bool fwd_on_stream(int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int y_f32, int ldx, int ldy) {
+    return use_stream() && !y_f32 && ldx % 8 == 0 && ldy % 8 == 0 && yh_bf16_fstream_ok(B, Hi, Wi, Cin, Cout, k, s);
+}
+
+extern "C" int yh_bf16_conv_fwd_blocks(int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int y_f32, int ldx, int ldy) {
+    if (fwd_on_stream(B, Hi, Wi, Cin, Cout, k, s, y_f32, ldx, ldy)) return yh_bf16_fstream_blocks(B, Hi, Wi, Cin, Cout, k);
+    const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
+    return (int)cdiv64((int64_t)B * Ho * Wo, GEMM_BM);
+}
+
+static int fwd_stream(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, float *bn_partials, int B,
+                      int Hi, int Wi, int Cin, int Cout, int k, void *stream) {
+    YH_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wf) & 15) == 0 && ldwf >= Cout,
+               "bf16 flat-stream forward: ld %% 8 == 0 and 16-byte aligned views required");
+    const int p = k / 2;
+    int tdy[9], tdx[9], tw[9];
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            const int t = kh * k + kw;
+            tdy[t] = kh - p; tdx[t] = kw - p; tw[t] = t;
+        }
+    return yh_bf16_fstream(x, nullptr, 0, ldx, wf, ldwf, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, k, 0, tdy, tdx, tw,
+                           (hipStream_t)stream);
+}
+
+// stride 1: dX = dY * flipped filter; one tap class, K = Cout (both tensors of a sibling pair), N = Cin
+static int bwd_data_stream(const void *dy, int lddy, const void *dy2, int kcout1, const void *wb, int ldwb, void *dx, int lddx, int B,
+                           int Hi, int Wi, int Cin, int Cout, int k, int accumulate, void *stream) {
+    YH_REQUIRE(lddy % 8 == 0 && lddx % 8 == 0 && (((uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)dx | (uintptr_t)wb) & 15) == 0 && ldwb >= Cin,
+               "bf16 flat-stream backward-data: ld %% 8 == 0 and 16-byte aligned views required");
+    const int p = k / 2;
+    int tdy[9], tdx[9], tw[9], nt = 0;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            tdy[nt] = p - kh; tdx[nt] = p - kw; tw[nt] = kh * k + kw;
+            ++nt;
+        }
+    return yh_bf16_fstream(dy, dy2, kcout1, lddy, wb, ldwb, nullptr, dx, lddx, nullptr, B, Hi, Wi, Cout, Cin, k, accumulate, tdy, tdx, tw,
+                           (hipStream_t)stream);
+}
+
+// The flat-stream kernels FORCED (tests, benchmarks): same contracts as yh_bf16_conv_fwd (bf16 output) / yh_bf16_conv_bwd_data at
+// stride 1; yh_bf16_conv_stream_blocks = 0 when the kernel cannot run the problem, else the BatchNorm partial rows it writes.
+extern "C" int yh_bf16_conv_stream_blocks(int B, int Hi, int Wi, int K, int N, int k) {
+    return yh_bf16_fstream_supported(B, Hi, Wi, K, N, k, 1) ? yh_bf16_fstream_blocks(B, Hi, Wi, K, N, k) : 0;
+}
+extern "C" int yh_bf16_conv_stream_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy,
+                                       float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, void *stream) {
+    YH_REQUIRE(yh_bf16_fstream_supported(B, Hi, Wi, Cin, Cout, k, 1), "bf16_conv_stream_fwd: unsupported problem");
+    return fwd_stream(x, ldx, wf, ldwf, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, k, stream);
+}
+extern "C" int yh_bf16_conv_stream_bwd_data(const void *dy, int lddy, const void *dy2, int kcout1, const void *wb, int ldwb, void *dx,
+                                            int lddx, int B, int Hi, int Wi, int Cin, int Cout, int k, int accumulate, void *stream) {
+    YH_REQUIRE(yh_bf16_fstream_supported(B, Hi, Wi, Cout, Cin, k, 1), "bf16_conv_stream_bwd_data: unsupported problem");
+    return bwd_data_stream(dy, lddy, dy2, kcout1, wb, ldwb, dx, lddx, B, Hi, Wi, Cin, Cout, k, accumulate, stream);
+}
+
 extern "C" int yh_bf16_conv_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, int y_f32,
                                 float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream) {
     YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2) && !(k == 1 && s == 2), "bf16_conv_fwd: unsupported k=%d s=%d", k, s);
     YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "bf16_conv_fwd: bad argument");
     YH_REQUIRE(ldx >= Cin && ldy >= Cout, "bf16_conv_fwd: ld smaller than channel count");
-    BfGemm g{};
+    if (fwd_on_stream(B, Hi, Wi, Cin, Cout, k, s, y_f32, ldx, ldy))
+        return fwd_stream(x, ldx, wf, ldwf, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, k, stream);
     const int p = k / 2;
+    BfGemm g{};
     fill_common(g, x, ldx, wf, ldwf, Hi, Wi, Cin, B);
     g.bias = bias; g.out = y; g.stats = bn_partials; g.out_f32 = y_f32 ? 1 : 0;
     g.Ho_f = (Hi + 2 * p - k) / s + 1; g.Wo_f = (Wi + 2 * p - k) / s + 1; g.ldo = ldy; g.N = Cout;
@@ -882,6 +942,8 @@ extern "C" int yh_bf16_conv_bwd_data(const void *dy, int lddy, const void *dy2, 
     YH_REQUIRE(lddy >= (dy2 ? kcout1 : Cout) && lddx >= Cin, "bf16_conv_bwd_data: ld smaller than channel count");
     YH_REQUIRE(!dy2 || (k == 1 && kcout1 > 0 && kcout1 < Cout), "bf16_conv_bwd_data: the two-source form is pointwise only");
     const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
+    if (use_stream() && yh_bf16_fstream_ok(B, Hi, Wi, Cout, Cin, k, s) && lddy % 8 == 0 && lddx % 8 == 0)
+        return bwd_data_stream(dy, lddy, dy2, kcout1, wb, ldwb, dx, lddx, B, Hi, Wi, Cin, Cout, k, accumulate, stream);
     BfGemmSet gs{};
     int ncls = 0;
     for (int ph = 0; ph < s; ++ph)

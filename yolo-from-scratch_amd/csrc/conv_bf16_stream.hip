@@ -353,3 +353,356 @@ int yh_bf16_wgrad_stream(const void *x, int ldx, const void *dy, int lddy, float
     if (pl.NI == 2) return pl.NJ == 2 ? launch_wgs<1, 2, 2>(pl, st) : launch_wgs<1, 2, 1>(pl, st);
     return pl.NJ == 2 ? launch_wgs<1, 1, 2>(pl, st) : launch_wgs<1, 1, 1>(pl, st);
 }
+
+// =====================================================================================================================
+// Forward / backward-data of the stride-1 layers as a flat stream:  out[f][n] (+)= sum_{tap, c} in[f + off(tap)][c] w[tap][c][n]
+// (backward-data = the same sum over dY with the flipped, transposed filter pack).
+//
+// A persistent 256-thread workgroup owns a contiguous range of 128-position tiles and a column block of 32 TN channels:
+//   * the weight block [taps][Cin/8][32 TN][8] is loaded into LDS ONCE per workgroup;
+//   * input positions travel HBM -> registers -> an LDS ring ONCE: the ring holds the 2 (XW + 1) positions of halo that the
+//     nine taps of consecutive tiles share (the segment kernel re-requested every input element nine times from L1 / L2);
+//     a slot is Cin * 2 + 16 bytes, so the 16 rows of a ds_read_b128 lane group start in 16 distinct bank quads;
+//   * loads run PD - 1 = 3 tiles ahead in three register sets, one barrier per tile publishes the next tile's 128 positions;
+//   * wave w multiplies rows 32 w .. 32 w + 31 of the tile against all 32 TN columns (A fragment shared by TN MFMAs);
+//   * epilogue: bias, rounding to bf16, BatchNorm sums of the ROUNDED values over real (non-padding) positions kept in
+//     registers across the whole tile range (ONE partial row per workgroup: a cheap bn_finalize), transpose through LDS,
+//     16-byte stores of the real positions only.
+namespace {
+
+struct FsP {
+    const bf16 *in, *in2;      // in2: channels >= ksplit come from a second tensor (the C3 sibling pair's backward-data)
+    const bf16 *w;             // pack [tap][Cin/8][ldw][8]
+    const float *bias;
+    bf16 *out;
+    float *stats;              // [gridDim.x][2][N]
+    int ksplit, ldw, ldi, ldo, N, accumulate;
+    int H, W, XW, VH, pad, Mflat;
+    unsigned xw_magic, vh_magic;
+    int xw_shift, vh_shift;
+    int ntile, tiles_per_wg;
+    int R, halo;               // ring slots; XW + 1 (3x3) or 0 (1x1)
+    int tapoff[9], tapw[9];
+};
+
+template <int KK>
+__device__ __forceinline__ bool fs_pixel(const FsP &g, int f, int &pix) {
+    if (KK == 1) {
+        pix = f;
+        return (unsigned)f < (unsigned)g.Mflat;
+    }
+    const bool in = (unsigned)f < (unsigned)g.Mflat;
+    const int ff = in ? f : 0;
+    const int q1 = yh_fast_div(ff, g.xw_magic, g.xw_shift), vx = ff - q1 * g.XW - g.pad;
+    const int b = yh_fast_div(q1, g.vh_magic, g.vh_shift), vy = q1 - b * g.VH - g.pad;
+    pix = (b * g.H + vy) * g.W + vx;
+    return in && (unsigned)vx < (unsigned)g.W && (unsigned)vy < (unsigned)g.H;
+}
+
+template <int KK, int CIN, int TN>
+__global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
+    constexpr int BM = 128, BN = 32 * TN, C8 = CIN / 8, KS = CIN / 16, PS = CIN * 2 + 16, PD = 4;
+    constexpr int NP = (BM * C8) / 256;          // 16-byte pieces per thread and tile
+    constexpr int CS = BN * 2 + 16;              // bytes per row of the epilogue staging tile
+    constexpr int PC = BN / 8;                   // 16-byte pieces per output row
+    static_assert(NP >= 1 && (BM * C8) % 256 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Ws = smem;                                  // [KK][C8][BN][16 bytes]
+    unsigned char *As = Ws + KK * C8 * BN * 16;                // [R][PS]
+    unsigned char *Cs = As + g.R * PS;                         // [BM][CS]
+    int *rowpix = (int *)(Cs + BM * CS);                       // [BM] output pixel of each tile row, -1 = padding position
+    float *red = (float *)(rowpix + BM);                       // [4][BN][2]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int T0 = blockIdx.x * g.tiles_per_wg;
+    int T1 = T0 + g.tiles_per_wg;
+    if (T1 > g.ntile) T1 = g.ntile;
+
+    // ---- weights: once per workgroup -------------------------------------------------------------------------------------
+    for (int e = t; e < KK * C8 * BN; e += 256) {
+        const int n = e % BN, q = e / BN, o = q % C8, u = q / C8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (n0 + n < g.ldw) v = *(const u32x4 *)(g.w + ((size_t)(g.tapw[u] * C8 + o) * g.ldw + n0 + n) * 8);
+        *(u32x4 *)(Ws + (size_t)e * 16) = v;
+    }
+
+    // ---- staging ------------------------------------------------------------------------------------------------------------
+    const unsigned char *ib = (const unsigned char *)g.in, *ib2 = (const unsigned char *)g.in2;
+    int ppix[NP], pch[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = t + 256 * i;
+        ppix[i] = e / C8;
+        pch[i] = e % C8;
+    }
+    u32x4 ra[PD][NP];
+    unsigned mk[PD];
+    // L(m): request the 128 positions [BM (m + PD) + halo, ...) (stored PD - 1 iterations later as "the new positions of tile m + PD")
+    auto issue = [&](int m, u32x4 (&a)[NP], unsigned &mko) __attribute__((always_inline)) {
+        unsigned mm = 0;
+        const int p0 = BM * (m + PD) + g.halo;
+        const bool live = m + PD <= T1;               // positions beyond the last tile's halo are never read
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int px;
+            const bool ok = fs_pixel<KK>(g, p0 + ppix[i], px) && live;
+            const int c = 8 * pch[i];
+            const bool second = g.in2 && c >= g.ksplit;
+            const unsigned off = ok ? (unsigned)(px * g.ldi + (second ? c - g.ksplit : c)) * 2u : 0u;
+            mm |= (unsigned)ok << i;
+            a[i] = *(const u32x4 *)((second ? ib2 : ib) + off);
+        }
+        mko = mm;
+    };
+    // ring cursors (wave-uniform): st = slot of position BM (n + 1) + halo, cb[u] = slot of position BM n + off(tap u)
+    const int warm = (2 * g.halo + BM - 1) / BM + 1;
+    const int nfirst = T0 - warm;
+    int st = wgs_mod(BM * (nfirst + 1) + g.halo, g.R);
+    int cb[KK];
+#pragma unroll
+    for (int u = 0; u < KK; ++u) cb[u] = wgs_mod(BM * nfirst + g.tapoff[u], g.R);
+    auto advance = [&]() __attribute__((always_inline)) {
+        st += BM; if (st >= g.R) st -= g.R;
+#pragma unroll
+        for (int u = 0; u < KK; ++u) { cb[u] += BM; if (cb[u] >= g.R) cb[u] -= g.R; }
+    };
+    auto store = [&](const u32x4 (&a)[NP], unsigned mki) __attribute__((always_inline)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int s = st + ppix[i];
+            if (s >= g.R) s -= g.R;
+            *(u32x4 *)(As + s * PS + pch[i] * 16) = (mki >> i) & 1u ? a[i] : z;
+        }
+    };
+
+    // ---- multiply: wave w = rows 32 w .. 32 w + 31; lane (r, h) holds A[row r][k = 8 h ..] and B[k = 8 h ..][col r] ----------
+    f32x16 acc[TN];
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+    const unsigned char *w_lane = Ws + (lh * BN + lr) * 16;
+    auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < KK; ++u) {
+            int s = cb[u] + 32 * wave + lr;
+            if (s >= g.R) s -= g.R;
+            const unsigned char *ap = As + s * PS + 16 * lh;
+            const unsigned char *wp = w_lane + (size_t)u * C8 * BN * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 av = *(const bf16x8 *)(ap + 32 * ks);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 bv = *(const bf16x8 *)(wp + (2 * ks * BN + 32 * j) * 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + 32 * j + lr;
+        bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+    }
+    auto epilogue = [&](int n) __attribute__((always_inline)) {
+        if (t < BM) {
+            int px;
+            rowpix[t] = fs_pixel<KK>(g, BM * n + t, px) ? px : -1;
+        }
+        __syncthreads();                                   // rowpix visible; every wave is past the previous tile's stores from Cs
+        float rv[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const i32x4 p4 = *(const i32x4 *)(rowpix + 32 * wave + 8 * q4 + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[4 * q4 + e] = p4[e] >= 0 ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            unsigned char *row = Cs + (32 * wave + yh_mfma_row(q, lh)) * CS + lr * 2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bf16 hv = (bf16)(acc[j][q] + bias_v[j]);
+                *(bf16 *)(row + j * 64) = hv;
+                const float vq = (float)hv * rv[q];
+                csum[j] += vq;
+                csq[j] += vq * (float)hv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (BM * PC) / 256; ++i) {
+            const int e = t + 256 * i, rl = e / PC, oc = e % PC;
+            const int px = rowpix[rl], nn = n0 + 8 * oc;
+            if (px >= 0 && nn < g.N) {
+                bf16x8 v = *(const bf16x8 *)(Cs + rl * CS + oc * 16);
+                bf16 *o = g.out + (size_t)px * g.ldo + nn;
+                if (g.accumulate) {
+                    const bf16x8 old = *(const bf16x8 *)o;
+                    const f32x8 sum = __builtin_convertvector(v, f32x8) + __builtin_convertvector(old, f32x8);
+                    v = __builtin_convertvector(sum, bf16x8);
+                }
+                *(bf16x8 *)o = v;
+            }
+        }
+    };
+
+    // ---- pipeline (same shape as the weight-gradient stream): iteration n stores the new positions of tile n + 1, requests
+    // those of tile n + PD, multiplies tile n; the first `warm` iterations only fill the ring ---------------------------------
+#pragma unroll
+    for (int p = 0; p < PD - 1; ++p) issue(nfirst - (PD - 1) + p, ra[p], mk[p]);
+    for (int n = nfirst; n < T1; n += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            if (n + p < T1) {
+                issue(n + p, ra[(p + PD - 1) % PD], mk[(p + PD - 1) % PD]);
+                store(ra[p], mk[p]);
+                __syncthreads();
+                if (n + p >= T0) {
+                    compute();
+                    epilogue(n + p);
+                }
+                advance();
+            }
+        }
+    }
+    if (g.stats) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) {
+                red[((wave * BN) + 32 * j + lr) * 2 + 0] = s;
+                red[((wave * BN) + 32 * j + lr) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < g.N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s += red[((w * BN) + t) * 2 + 0];
+                q += red[((w * BN) + t) * 2 + 1];
+            }
+            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = s;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = q;
+        }
+    }
+}
+
+struct FsPlan {
+    FsP g;
+    int KK, CIN, TN, gx, gy;
+    size_t smem;
+    bool ok;
+};
+
+// K = channels of the streamed tensor (16 / 32 / 64 / 128), N = output channels (bf16 output, a multiple of 8)
+void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
+    FsP &g = pl.g;
+    pl.ok = false;
+    pl.KK = k * k;
+    pl.CIN = K;
+    if (!(K == 16 || K == 32 || K == 64 || K == 128) || (k != 1 && k != 3) || N % 8 != 0 || N < 8) return;
+    if (k == 3 && K > 64) return;                               // the weight block + halo ring of a 128-channel 3x3 layer exceed the LDS
+    g.H = H; g.W = W; g.pad = k / 2; g.XW = W + 2 * g.pad; g.VH = H + 2 * g.pad; g.N = N;
+    g.Mflat = B * g.VH * g.XW;
+    if (g.Mflat >= (1 << 29)) return;
+    yh_set_magic((unsigned)g.XW, g.xw_magic, g.xw_shift);
+    yh_set_magic((unsigned)g.VH, g.vh_magic, g.vh_shift);
+    g.halo = k == 3 ? g.XW + 1 : 0;
+    g.R = (2 * 128 + 2 * g.halo + 15) & ~15;
+    // column block: all of N up to 128 columns (k = 1) / 64 columns (k = 3), so the input is streamed once
+    const int cap = k == 3 ? 64 : 128;
+    pl.TN = N > 64 ? (cap >= 128 ? 4 : 2) : (N > 32 ? 2 : 1);
+    const int BN = 32 * pl.TN;
+    pl.gy = cdiv(N, BN);
+    g.ntile = cdiv(g.Mflat, 128);
+    int gx = 256 / pl.gy;                                        // one workgroup per CU
+    if (gx < 1) gx = 1;
+    if (gx > g.ntile) gx = g.ntile;
+    g.tiles_per_wg = cdiv(g.ntile, gx);
+    pl.gx = cdiv(g.ntile, g.tiles_per_wg);
+    const int PS = K * 2 + 16;
+    pl.smem = (size_t)pl.KK * (K / 8) * BN * 16 + (size_t)g.R * PS + (size_t)128 * (BN * 2 + 16) + 128 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
+    if (pl.smem > 160 * 1024) return;
+    pl.ok = true;
+}
+
+template <int KK, int CIN, int TN>
+int launch_fs(const FsPlan &pl, hipStream_t st) {
+    auto kern = bf16_fstream_kernel<KK, CIN, TN>;
+    if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
+    hipLaunchKernelGGL(kern, dim3(pl.gx, pl.gy), dim3(256), pl.smem, st, pl.g);
+    YH_CHECK_LAUNCH("bf16_fstream");
+    return 0;
+}
+
+template <int KK, int CIN>
+int launch_fs_tn(const FsPlan &pl, hipStream_t st) {
+    if (pl.TN == 1) return launch_fs<KK, CIN, 1>(pl, st);
+    if (pl.TN == 2) return launch_fs<KK, CIN, 2>(pl, st);
+    if (KK == 1 && pl.TN == 4) return launch_fs<1, CIN, 4>(pl, st);
+    yh_set_error("bf16_fstream: column block of %d not instantiated", 32 * pl.TN);
+    return YH_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+// Where the flat stream measured faster than the gather GEMM (tools/conv_bench_bf16.py, batch 64, us stream / gather): 3x3 with
+// K <= 32 (16 -> 16 at 160x160: 78 / 93, 32 -> 32 at 80x80: 32 / 36) and the pointwise layers over >= 1 M pixels (32 -> 16 at
+// 160x160: 51 / 60, 32 -> 32: 52 / 59).  With K = 64 the 74 KB weight block + halo ring leave ONE workgroup of four waves per
+// CU and its epilogue / staging serialise with the MFMAs (64 -> 64 3x3 at 80x80: 69 / 63 us): those stay on the gather GEMM.
+bool yh_bf16_fstream_supported(int B, int H, int W, int K, int N, int k, int s) {
+    if (s != 1) return false;
+    FsPlan pl{};
+    plan_fs(pl, B, H, W, K, N, k);
+    return pl.ok;
+}
+bool yh_bf16_fstream_ok(int B, int H, int W, int K, int N, int k, int s) {
+    if (!yh_bf16_fstream_supported(B, H, W, K, N, k, s)) return false;
+    return k == 3 ? K <= 32 : (int64_t)B * H * W >= (1 << 20);
+}
+
+int yh_bf16_fstream_blocks(int B, int H, int W, int K, int N, int k) {
+    FsPlan pl{};
+    plan_fs(pl, B, H, W, K, N, k);
+    return pl.ok ? pl.gx : 0;
+}
+
+// taps: tapoff (dy, dx as flat displacement) and pack index per tap, nTaps = k * k entries
+int yh_bf16_fstream(const void *in, const void *in2, int ksplit, int ldi, const void *w, int ldw, const float *bias, void *out, int ldo,
+                    float *stats, int B, int H, int W, int K, int N, int k, int accumulate, const int *tap_dy, const int *tap_dx,
+                    const int *tap_w, hipStream_t st) {
+    FsPlan pl{};
+    plan_fs(pl, B, H, W, K, N, k);
+    YH_REQUIRE(pl.ok, "bf16_fstream: unsupported problem K=%d N=%d k=%d", K, N, k);
+    YH_REQUIRE((int64_t)B * H * W * ldi * 2 < (1ll << 31), "bf16_fstream: tensor exceeds the 32-bit byte-offset range");
+    FsP &g = pl.g;
+    g.in = (const bf16 *)in; g.in2 = (const bf16 *)in2; g.ksplit = ksplit; g.ldi = ldi; g.w = (const bf16 *)w; g.ldw = ldw;
+    g.bias = bias; g.out = (bf16 *)out; g.ldo = ldo; g.stats = stats; g.accumulate = accumulate;
+    for (int u = 0; u < k * k; ++u) {
+        g.tapoff[u] = tap_dy[u] * g.XW + tap_dx[u];
+        g.tapw[u] = tap_w[u];
+    }
+    if (k == 3) {
+        switch (K) {
+            case 16: return launch_fs_tn<9, 16>(pl, st);
+            case 32: return launch_fs_tn<9, 32>(pl, st);
+            default: return launch_fs_tn<9, 64>(pl, st);
+        }
+    }
+    switch (K) {
+        case 16: return launch_fs_tn<1, 16>(pl, st);
+        case 32: return launch_fs_tn<1, 32>(pl, st);
+        case 64: return launch_fs_tn<1, 64>(pl, st);
+        default: return launch_fs_tn<1, 128>(pl, st);
+    }
+}

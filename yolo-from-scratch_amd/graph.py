@@ -378,6 +378,9 @@ class Plan:
                 # narrow high-resolution 3x3 layers: direct kernel (LDS halo patch, filter in registers, 16-wide MFMA tiles)
                 nar_ok = use_narrow and r.k == 3 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and r.x.off % 4 == 0
                 r.narrow_f = bool(nar_ok and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s))
+                if use_narrow and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16 \
+                        and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s):
+                    r.narrow_f = True                     # first layer: the same direct MFMA kernel with CIN = 4 (padded) channels
                 r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
                 if r.narrow_f:
                     r.wino_f = False
@@ -569,7 +572,8 @@ class Plan:
             packs.append((r.weight.data_ptr(), r.wf.data_ptr(), r.wb.data_ptr() if r.need_dx else 0, r.cout, cin_real, kk,
                           r.cin, r.ldwf, r.ldwb, koff, kpad))
             M = r.x.B * r.Ho * r.Wo
-            r.nblk = lib.yh_bf16_conv_blocks(M)
+            r.nblk = lib.yh_bf16_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, 0 if r.bn is not None else 1, r.x.ld,
+                                                 r.cout if r.bn is not None else r.out.ld)
             # narrow high-resolution 3x3 layers (first layer, stem[3], the 16-channel bottleneck): the direct kernels of the fp32
             # path with bf16 storage (conv_narrow.hip); cin_k = channels the kernel reads (4 of the first layer's 8 padded ones)
             use_nar = r.k == 3 and r.bn is not None and r.x.ld % 4 == 0 and r.x.off % 4 == 0
