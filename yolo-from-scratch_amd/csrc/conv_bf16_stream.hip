@@ -359,7 +359,7 @@ int yh_bf16_wgrad_stream(const void *x, int ldx, const void *dy, int lddy, float
 // (backward-data = the same sum over dY with the flipped, transposed filter pack).
 //
 // A persistent 256-thread workgroup owns a contiguous range of 128-position tiles and a column block of 32 TN channels:
-//   * the weight block [taps][Cin/8][32 TN][8] is loaded into LDS ONCE per workgroup;
+//   * each wave keeps its B fragments (taps x k-steps x column tiles, <= 144 registers) in REGISTERS for its whole tile range;
 //   * input positions travel HBM -> registers -> an LDS ring ONCE: the ring holds the 2 (XW + 1) positions of halo that the
 //     nine taps of consecutive tiles share (the segment kernel re-requested every input element nine times from L1 / L2);
 //     a slot is Cin * 2 + 16 bytes, so the 16 rows of a ds_read_b128 lane group start in 16 distinct bank quads;
@@ -399,40 +399,51 @@ __device__ __forceinline__ bool fs_pixel(const FsP &g, int f, int &pix) {
     return in && (unsigned)vx < (unsigned)g.W && (unsigned)vy < (unsigned)g.H;
 }
 
-template <int KK, int CIN, int TN>
-__global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
+// WN = 1: four waves, each 32 rows x all 32 TN columns.  WN = 2: eight waves (two per SIMD: one wave's fragment reads, epilogue
+// and staging run under the other's MFMAs), wave (wm, wn) = 32 rows x columns [16 TN wn, 16 TN (wn + 1)).
+template <int KK, int CIN, int TN, int WN>
+__global__ __launch_bounds__(256 * WN, WN) void bf16_fstream_kernel(const FsP g) {
     constexpr int BM = 128, BN = 32 * TN, C8 = CIN / 8, KS = CIN / 16, PS = CIN * 2 + 16, PD = 4;
-    constexpr int NP = (BM * C8) / 256;          // 16-byte pieces per thread and tile
+    constexpr int NTH = 256 * WN, TW = TN / WN;  // threads; column tiles per wave
+    constexpr int NP = (BM * C8) / NTH;          // 16-byte pieces per thread and tile
     constexpr int CS = BN * 2 + 16;              // bytes per row of the epilogue staging tile
     constexpr int PC = BN / 8;                   // 16-byte pieces per output row
-    static_assert(NP >= 1 && (BM * C8) % 256 == 0, "tile shape");
+    static_assert(NP >= 1 && (BM * C8) % NTH == 0 && TN % WN == 0 && (BM * PC) % NTH == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Ws = smem;                                  // [KK][C8][BN][16 bytes]
-    unsigned char *As = Ws + KK * C8 * BN * 16;                // [R][PS]
+    unsigned char *As = smem;                                  // [R][PS]
     unsigned char *Cs = As + g.R * PS;                         // [BM][CS]
     int *rowpix = (int *)(Cs + BM * CS);                       // [BM] output pixel of each tile row, -1 = padding position
     float *red = (float *)(rowpix + BM);                       // [4][BN][2]
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int t = threadIdx.x, lane = t & 63, wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave = wave_all & 3, cbw = 32 * TW * (wave_all >> 2);      // row group; first column of this wave's tiles
     const int lr = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const int T0 = blockIdx.x * g.tiles_per_wg;
     int T1 = T0 + g.tiles_per_wg;
     if (T1 > g.ntile) T1 = g.ntile;
 
-    // ---- weights: once per workgroup -------------------------------------------------------------------------------------
-    for (int e = t; e < KK * C8 * BN; e += 256) {
-        const int n = e % BN, q = e / BN, o = q % C8, u = q / C8;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (n0 + n < g.ldw) v = *(const u32x4 *)(g.w + ((size_t)(g.tapw[u] * C8 + o) * g.ldw + n0 + n) * 8);
-        *(u32x4 *)(Ws + (size_t)e * 16) = v;
-    }
+    // ---- weights: this wave's B fragments live in REGISTERS for the whole kernel (the pack layout [tap][K/8][ldw][8] is the
+    // fragment layout: lane (col r, h) takes the 16 bytes of octet 2 ks + h, column r).  No LDS footprint, no LDS read per MFMA
+    // for B: at two waves per SIMD the LDS port was as busy as the matrix pipe with both operands coming from it. -----------
+    bf16x8 bfr[KK * KS][TW];
+#pragma unroll
+    for (int u = 0; u < KK; ++u)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int n = n0 + cbw + 32 * j + lr;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (n < g.ldw) v = *(const u32x4 *)(g.w + ((size_t)(g.tapw[u] * C8 + 2 * ks + lh) * g.ldw + n) * 8);
+                bfr[u * KS + ks][j] = __builtin_bit_cast(bf16x8, v);
+            }
 
     // ---- staging ------------------------------------------------------------------------------------------------------------
     const unsigned char *ib = (const unsigned char *)g.in, *ib2 = (const unsigned char *)g.in2;
     int ppix[NP], pch[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = t + 256 * i;
+        const int e = t + NTH * i;
         ppix[i] = e / C8;
         pch[i] = e % C8;
     }
@@ -478,14 +489,13 @@ __global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
     };
 
     // ---- multiply: wave w = rows 32 w .. 32 w + 31; lane (r, h) holds A[row r][k = 8 h ..] and B[k = 8 h ..][col r] ----------
-    f32x16 acc[TN];
-    float csum[TN], csq[TN];
+    f32x16 acc[TW];
+    float csum[TW], csq[TW];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
-    const unsigned char *w_lane = Ws + (lh * BN + lr) * 16;
+    for (int j = 0; j < TW; ++j) csum[j] = csq[j] = 0.f;
     auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TW; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
@@ -493,22 +503,18 @@ __global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
             int s = cb[u] + 32 * wave + lr;
             if (s >= g.R) s -= g.R;
             const unsigned char *ap = As + s * PS + 16 * lh;
-            const unsigned char *wp = w_lane + (size_t)u * C8 * BN * 16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 av = *(const bf16x8 *)(ap + 32 * ks);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bf16x8 bv = *(const bf16x8 *)(wp + (2 * ks * BN + 32 * j) * 16);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < TW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bfr[u * KS + ks][j], acc[j], 0, 0, 0);
             }
         }
     };
-    float bias_v[TN];
+    float bias_v[TW];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + 32 * j + lr;
+    for (int j = 0; j < TW; ++j) {
+        const int n = n0 + cbw + 32 * j + lr;
         bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
     }
     auto epilogue = [&](int n) __attribute__((always_inline)) {
@@ -526,9 +532,9 @@ __global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            unsigned char *row = Cs + (32 * wave + yh_mfma_row(q, lh)) * CS + lr * 2;
+            unsigned char *row = Cs + (32 * wave + yh_mfma_row(q, lh)) * CS + (cbw + lr) * 2;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TW; ++j) {
                 const bf16 hv = (bf16)(acc[j][q] + bias_v[j]);
                 *(bf16 *)(row + j * 64) = hv;
                 const float vq = (float)hv * rv[q];
@@ -538,8 +544,8 @@ __global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < (BM * PC) / 256; ++i) {
-            const int e = t + 256 * i, rl = e / PC, oc = e % PC;
+        for (int i = 0; i < (BM * PC) / NTH; ++i) {
+            const int e = t + NTH * i, rl = e / PC, oc = e % PC;
             const int px = rowpix[rl], nn = n0 + 8 * oc;
             if (px >= 0 && nn < g.N) {
                 bf16x8 v = *(const bf16x8 *)(Cs + rl * CS + oc * 16);
@@ -576,11 +582,11 @@ __global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
     if (g.stats) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TW; ++j) {
             const float s = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
             if (lh == 0) {
-                red[((wave * BN) + 32 * j + lr) * 2 + 0] = s;
-                red[((wave * BN) + 32 * j + lr) * 2 + 1] = q;
+                red[((wave * BN) + cbw + 32 * j + lr) * 2 + 0] = s;
+                red[((wave * BN) + cbw + 32 * j + lr) * 2 + 1] = q;
             }
         }
         __syncthreads();
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void bf16_fstream_kernel(const FsP g) {
 
 struct FsPlan {
     FsP g;
-    int KK, CIN, TN, gx, gy;
+    int KK, CIN, TN, WN, gx, gy;
     size_t smem;
     bool ok;
 };
@@ -631,35 +637,39 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     g.tiles_per_wg = cdiv(g.ntile, gx);
     pl.gx = cdiv(g.ntile, g.tiles_per_wg);
     const int PS = K * 2 + 16;
-    pl.smem = (size_t)pl.KK * (K / 8) * BN * 16 + (size_t)g.R * PS + (size_t)128 * (BN * 2 + 16) + 128 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
+    pl.smem = (size_t)g.R * PS + (size_t)128 * (BN * 2 + 16) + 128 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
     if (pl.smem > 160 * 1024) return;
+    pl.WN = (pl.TN >= 2 && K >= 32) ? 2 : 1;                    // eight waves wherever a wave still owns a whole 32-column tile
+    if (pl.KK * (K / 16) * (pl.TN / pl.WN) * 4 > 160) return;   // B fragments in registers: taps * k-steps * column tiles * 4 VGPRs
     pl.ok = true;
 }
 
-template <int KK, int CIN, int TN>
+template <int KK, int CIN, int TN, int WN>
 int launch_fs(const FsPlan &pl, hipStream_t st) {
-    auto kern = bf16_fstream_kernel<KK, CIN, TN>;
+    auto kern = bf16_fstream_kernel<KK, CIN, TN, WN>;
     if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
-    hipLaunchKernelGGL(kern, dim3(pl.gx, pl.gy), dim3(256), pl.smem, st, pl.g);
+    hipLaunchKernelGGL(kern, dim3(pl.gx, pl.gy), dim3(256 * WN), pl.smem, st, pl.g);
     YH_CHECK_LAUNCH("bf16_fstream");
     return 0;
 }
 
 template <int KK, int CIN>
 int launch_fs_tn(const FsPlan &pl, hipStream_t st) {
-    if (pl.TN == 1) return launch_fs<KK, CIN, 1>(pl, st);
-    if (pl.TN == 2) return launch_fs<KK, CIN, 2>(pl, st);
-    if (KK == 1 && pl.TN == 4) return launch_fs<1, CIN, 4>(pl, st);
+    constexpr int W2 = CIN >= 32 ? 2 : 1;
+    if (pl.TN == 1) return launch_fs<KK, CIN, 1, 1>(pl, st);
+    if (pl.TN == 2) return launch_fs<KK, CIN, 2, W2>(pl, st);
+    if (KK == 1 && pl.TN == 4) return launch_fs<1, CIN, 4, W2>(pl, st);
     yh_set_error("bf16_fstream: column block of %d not instantiated", 32 * pl.TN);
     return YH_E_UNSUPPORTED;
 }
 
 }  // namespace
 
-// Where the flat stream measured faster than the gather GEMM (tools/conv_bench_bf16.py, batch 64, us stream / gather): 3x3 with
-// K <= 32 (16 -> 16 at 160x160: 78 / 93, 32 -> 32 at 80x80: 32 / 36) and the pointwise layers over >= 1 M pixels (32 -> 16 at
-// 160x160: 51 / 60, 32 -> 32: 52 / 59).  With K = 64 the 74 KB weight block + halo ring leave ONE workgroup of four waves per
-// CU and its epilogue / staging serialise with the MFMAs (64 -> 64 3x3 at 80x80: 69 / 63 us): those stay on the gather GEMM.
+// Where the flat stream measured faster than (or equal to) the gather GEMM (tools/fs_bench.py, batch 64, us stream / gather):
+// every supported 3x3 (64 -> 64 at 80x80: 50 / 68-74, at 40x40: 20 / 24; 32 -> 32 at 80x80: 32-34 / 32-36; 16 -> 16 at
+// 160x160: 78 / 93); pointwise layers over >= 1 M pixels (32 -> 16 at 160x160: 51 / 60) or with N >= 64 and K <= N
+// (64 -> 64 at 80x80: 24.5 / 25.0, 128 -> 128 at 40x40: 17.9 / 18.1 -- equal, and ONE BatchNorm partial row per workgroup
+// instead of one per 128 pixels); wide-K narrow-N pointwise layers stay on the gather GEMM (128 -> 32 at 80x80: 28.9 / 26.1).
 bool yh_bf16_fstream_supported(int B, int H, int W, int K, int N, int k, int s) {
     if (s != 1) return false;
     FsPlan pl{};
@@ -668,7 +678,7 @@ bool yh_bf16_fstream_supported(int B, int H, int W, int K, int N, int k, int s) 
 }
 bool yh_bf16_fstream_ok(int B, int H, int W, int K, int N, int k, int s) {
     if (!yh_bf16_fstream_supported(B, H, W, K, N, k, s)) return false;
-    return k == 3 ? K <= 32 : (int64_t)B * H * W >= (1 << 20);
+    return k == 3 || (int64_t)B * H * W >= (1 << 20) || (N >= 64 && K <= N);
 }
 
 int yh_bf16_fstream_blocks(int B, int H, int W, int K, int N, int k) {
