@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 export YH_OVERLAP=0
-rocprofv3 --kernel-trace   -d $R/gpurun_out/sp_${tag}_trace -o t -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/sp_${tag}_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/sp_${tag}_fetch -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/sp_${tag}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/sp_${tag}_write -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/sp_${tag}_write.log 2>&1
+rocprofv3 --kernel-trace   -d $R/gpurun_out/sp_${tag}_trace -o t -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/sp_${tag}_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/sp_${tag}_fetch -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/sp_${tag}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/sp_${tag}_write -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $R/gpurun_out/sp_${tag}_write.log 2>&1
 echo "collected $tag"

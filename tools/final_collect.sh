@@ -4,10 +4,10 @@
 # when the profile's stamp equals the tree's hash).  Outputs land in gpurun_out/; copy them with tools/store_evidence.py.
 set -e
 bash tools/collect_step_profile.sh f32
-python tools/step_profile.py gpurun_out/sp_f32_trace/t_results.db gpurun_out/sp_f32_fetch/c_results.db gpurun_out/sp_f32_write/c_results.db profiles/r02_step_profile_f32.json > gpurun_out/sp_f32.log 2>&1
-python tools/kernel_stats.py gpurun_out/sp_f32_trace/t_results.db profiles/r02_kernel_stats_f32_serial.csv --per-step 5 > /dev/null 2>&1
+python3 tools/step_profile.py gpurun_out/sp_f32_trace/t_results.db gpurun_out/sp_f32_fetch/c_results.db gpurun_out/sp_f32_write/c_results.db profiles/r03_step_profile_f32.json > gpurun_out/sp_f32.log 2>&1
+python3 tools/kernel_stats.py gpurun_out/sp_f32_trace/t_results.db profiles/r03_kernel_stats_f32_serial.csv --per-step 5 > /dev/null 2>&1
 bash tools/collect_step_profile.sh bf16 YH_BENCH_DTYPE=bf16 YH_BENCH_SHAPE=80,640,64
-python tools/step_profile.py gpurun_out/sp_bf16_trace/t_results.db gpurun_out/sp_bf16_fetch/c_results.db gpurun_out/sp_bf16_write/c_results.db profiles/r02_step_profile_bf16.json > gpurun_out/sp_bf16.log 2>&1
-cp profiles/r02_step_profile_f32.json profiles/r02_step_profile_bf16.json profiles/r02_kernel_stats_f32_serial.csv gpurun_out/
-python bench.py > gpurun_out/ev_bench_f32.json 2> gpurun_out/ev_bench_f32.err
+python3 tools/step_profile.py gpurun_out/sp_bf16_trace/t_results.db gpurun_out/sp_bf16_fetch/c_results.db gpurun_out/sp_bf16_write/c_results.db profiles/r03_step_profile_bf16.json > gpurun_out/sp_bf16.log 2>&1
+cp profiles/r03_step_profile_f32.json profiles/r03_step_profile_bf16.json profiles/r03_kernel_stats_f32_serial.csv gpurun_out/
+python3 bench.py > gpurun_out/ev_bench_f32.json 2> gpurun_out/ev_bench_f32.err
 echo final2

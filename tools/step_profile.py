@@ -5,10 +5,10 @@ MI355X_MICROARCH.md, rocprofv3 PMC slots).  FETCH_SIZE is doubled (gfx950 tallie
 at 64 bytes; checked here against the nchw_to_nhwc launch whose traffic is known), counter unit KiB.
 
     cd /tmp && export TMPDIR=/tmp
-    YH_OVERLAP=0 rocprofv3 --kernel-trace   -d $R/gpurun_out/sp_trace -o t -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline
-    YH_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/sp_fetch -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
-    YH_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/sp_write -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
-    python tools/step_profile.py gpurun_out/sp_trace/t_results.db gpurun_out/sp_fetch/c_results.db gpurun_out/sp_write/c_results.db profiles/r02_step_profile_f32.json
+    YH_OVERLAP=0 rocprofv3 --kernel-trace   -d $R/gpurun_out/sp_trace -o t -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras
+    YH_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/sp_fetch -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras
+    YH_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/sp_write -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras
+    python tools/step_profile.py gpurun_out/sp_trace/t_results.db gpurun_out/sp_fetch/c_results.db gpurun_out/sp_write/c_results.db profiles/r03_step_profile_f32.json
 (the same with YH_BENCH_DTYPE=bf16 YH_BENCH_SHAPE=80,640,64 for the bf16 path)
 """
 import json
@@ -20,10 +20,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from provenance import stamp
 
-FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "stem_conv_kernel", "bf16_gemm_kernel",
-            "narrow_conv_kernel")
+FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "bf16_gemm_kernel",
+            "bf16_fstream_kernel", "narrow_conv_kernel")
 DGRAD_ONLY = ("narrow_dgrad_s2_kernel",)
-WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "wino_wgrad_lds_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "wgrad_reduce")
+WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "wino_wgrad_lds_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "bf16_wgrad_stream_kernel", "wgrad_reduce")
 
 
 def short(name):
@@ -103,7 +103,7 @@ def main():
            "calibration": {"kernel": "nchw_to_nhwc (first launch of the step: reads the NCHW fp32 batch with 4-byte loads)",
                            "FETCH_SIZE_bytes_raw": calib.get("fetch"), "WRITE_SIZE_bytes": calib.get("write")},
            "method": "rocprofv3 --kernel-trace (time, mean over steps) and --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (last step) "
-                     "over `YH_OVERLAP=0 python3 bench.py --no-cpu-baseline --no-roofline`; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE "
+                     "over `YH_OVERLAP=0 python3 bench.py --no-cpu-baseline --no-roofline --no-extras`; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE "
                      "(gfx950 reports half the bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md section HBM); tools/step_profile.py"}
     json.dump(doc, open(outp, "w"), indent=1)
     print(json.dumps({"groups": grp, "top": dict(list(doc["kernels"].items())[:12])}, indent=1))
