@@ -5,7 +5,11 @@ is raised.  Nothing here touches torch; callers pass raw device addresses (tenso
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import sys
+import threading
+import weakref
 import os
 import re
 
@@ -214,9 +218,11 @@ class Context:
                 "join_event": join.value}
 
     def close(self):
-        if self.handle is not None and _lib is not None:
-            _lib.yh_destroy(self.handle)
-        self.handle = None
+        """Destroy the native context (waits for its side stream).  Skipped while the interpreter is shutting down: the HIP
+        runtime may already be gone, and the process is about to release everything anyway."""
+        h, self.handle = self.handle, None
+        if h is not None and _lib is not None and not sys.is_finalizing():
+            _lib.yh_destroy(h)
 
     def __del__(self):
         try:
@@ -225,17 +231,32 @@ class Context:
             pass
 
 
-_contexts = {}
+# The default context of a host thread lives in thread-local storage: it is released with its thread (no leak under thread
+# churn, and a recycled thread ident can never inherit another thread's context); an atexit hook closes the contexts that are
+# still alive before torch / HIP tear down.
+_tls = threading.local()
+_live = weakref.WeakSet()
 
 
 def context_for(device_index: int) -> Context:
     """The default execution context of this host thread for one device."""
-    import threading
-    key = (int(device_index), threading.get_ident())
-    ctx = _contexts.get(key)
+    per_dev = getattr(_tls, "contexts", None)
+    if per_dev is None:
+        per_dev = _tls.contexts = {}
+    ctx = per_dev.get(int(device_index))
     if ctx is None:
-        ctx = _contexts[key] = Context()
+        ctx = per_dev[int(device_index)] = Context()
+        _live.add(ctx)
     return ctx
+
+
+@atexit.register
+def _close_contexts():
+    for ctx in list(_live):
+        try:
+            ctx.close()
+        except Exception:
+            pass
 
 
 def set_overlap(enable: bool, device_index: int = 0):
