@@ -380,7 +380,7 @@ struct FsP {
     int H, W, XW, VH, pad, Mflat;
     unsigned xw_magic, vh_magic;
     int xw_shift, vh_shift;
-    int ntile, tiles_per_wg;
+    int ntile, tiles_per_wg, gx, gy;
     int R, halo;               // ring slots; XW + 1 (3x3) or 0 (1x1)
     int tapoff[9], tapw[9];
 };
@@ -401,8 +401,10 @@ __device__ __forceinline__ bool fs_pixel(const FsP &g, int f, int &pix) {
 
 // WN = 1: four waves, each 32 rows x all 32 TN columns.  WN = 2: eight waves (two per SIMD: one wave's fragment reads, epilogue
 // and staging run under the other's MFMAs), wave (wm, wn) = 32 rows x columns [16 TN wn, 16 TN (wn + 1)).
-template <int KK, int CIN, int TN, int WN>
-__global__ __launch_bounds__(256 * WN, WN) void bf16_fstream_kernel(const FsP g) {
+// OCC = 2: two four-wave workgroups per CU (column blocks of 32: the two blocks of a 64-column layer are independent workgroups
+// whose stage / multiply / epilogue phases drift apart and overlap, which the barriers of one eight-wave workgroup prevent).
+template <int KK, int CIN, int TN, int WN, int OCC>
+__global__ __launch_bounds__(256 * WN, WN * OCC) void bf16_fstream_kernel(const FsP g) {
     constexpr int BM = 128, BN = 32 * TN, C8 = CIN / 8, KS = CIN / 16, PS = CIN * 2 + 16, PD = 4;
     constexpr int NTH = 256 * WN, TW = TN / WN;  // threads; column tiles per wave
     constexpr int NP = (BM * C8) / NTH;          // 16-byte pieces per thread and tile
@@ -417,8 +419,23 @@ __global__ __launch_bounds__(256 * WN, WN) void bf16_fstream_kernel(const FsP g)
     const int t = threadIdx.x, lane = t & 63, wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wave = wave_all & 3, cbw = 32 * TW * (wave_all >> 2);      // row group; first column of this wave's tiles
     const int lr = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.y * BN;
-    const int T0 = blockIdx.x * g.tiles_per_wg;
+    // 1-D grid; the gy column blocks that stream the SAME tile range get consecutive slots of one XCD (workgroups b and b + 8
+    // share an XCD and its L2): the second reader of a line finds it there.  Bijective (partial trailing group: plain order).
+    int bx, by;
+    {
+        const int lin = blockIdx.x, per = 8 * g.gy, full = (g.gx >> 3) * per;
+        if (lin < full) {
+            const int grp = lin / per, r = lin - grp * per;
+            bx = grp * 8 + (r & 7);
+            by = r >> 3;
+        } else {
+            const int r = lin - full, rem = g.gx & 7;
+            bx = (g.gx & ~7) + r % rem;
+            by = r / rem;
+        }
+    }
+    const int n0 = by * BN;
+    const int T0 = bx * g.tiles_per_wg;
     int T1 = T0 + g.tiles_per_wg;
     if (T1 > g.ntile) T1 = g.ntile;
 
@@ -597,15 +614,15 @@ __global__ __launch_bounds__(256 * WN, WN) void bf16_fstream_kernel(const FsP g)
                 s += red[((w * BN) + t) * 2 + 0];
                 q += red[((w * BN) + t) * 2 + 1];
             }
-            g.stats[((size_t)blockIdx.x * 2 + 0) * g.N + n0 + t] = s;
-            g.stats[((size_t)blockIdx.x * 2 + 1) * g.N + n0 + t] = q;
+            g.stats[((size_t)bx * 2 + 0) * g.N + n0 + t] = s;
+            g.stats[((size_t)bx * 2 + 1) * g.N + n0 + t] = q;
         }
     }
 }
 
 struct FsPlan {
     FsP g;
-    int KK, CIN, TN, WN, gx, gy;
+    int KK, CIN, TN, WN, OCC, gx, gy;
     size_t smem;
     bool ok;
 };
@@ -628,14 +645,22 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     // column block: all of N up to 128 columns (k = 1) / 64 columns (k = 3), so the input is streamed once
     const int cap = k == 3 ? 64 : 128;
     pl.TN = N > 64 ? (cap >= 128 ? 4 : 2) : (N > 32 ? 2 : 1);
+    // four-wave workgroups with one 32-column block can run TWO per CU (their phases drift apart and overlap; measured on the
+    // 3x3 layers, us at one / two per CU: 32 -> 32 at 80x80 34 / 26, 16 -> 16 at 160x160 74 / 52; 64 -> 64 would need column
+    // blocks of 32 and two passes over the input: 50 / 57, so it keeps the eight-wave form)
+#ifdef YH_WGS_TUNE
+    if (getenv("YH_FS_TN1") && k == 1 && K <= 64) pl.TN = 1;
+#endif
+    pl.OCC = (pl.TN == 1 && K <= (k == 3 ? 32 : 64)) ? 2 : 1;
     const int BN = 32 * pl.TN;
     pl.gy = cdiv(N, BN);
     g.ntile = cdiv(g.Mflat, 128);
-    int gx = 256 / pl.gy;                                        // one workgroup per CU
+    int gx = 256 * pl.OCC / pl.gy;                               // OCC workgroups per CU
     if (gx < 1) gx = 1;
     if (gx > g.ntile) gx = g.ntile;
     g.tiles_per_wg = cdiv(g.ntile, gx);
     pl.gx = cdiv(g.ntile, g.tiles_per_wg);
+    g.gx = pl.gx; g.gy = pl.gy;
     const int PS = K * 2 + 16;
     pl.smem = (size_t)g.R * PS + (size_t)128 * (BN * 2 + 16) + 128 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
     if (pl.smem > 160 * 1024) return;
@@ -644,11 +669,11 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     pl.ok = true;
 }
 
-template <int KK, int CIN, int TN, int WN>
+template <int KK, int CIN, int TN, int WN, int OCC = 1>
 int launch_fs(const FsPlan &pl, hipStream_t st) {
-    auto kern = bf16_fstream_kernel<KK, CIN, TN, WN>;
+    auto kern = bf16_fstream_kernel<KK, CIN, TN, WN, OCC>;
     if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
-    hipLaunchKernelGGL(kern, dim3(pl.gx, pl.gy), dim3(256 * WN), pl.smem, st, pl.g);
+    hipLaunchKernelGGL(kern, dim3(pl.gx * pl.gy), dim3(256 * WN), pl.smem, st, pl.g);
     YH_CHECK_LAUNCH("bf16_fstream");
     return 0;
 }
@@ -656,6 +681,9 @@ int launch_fs(const FsPlan &pl, hipStream_t st) {
 template <int KK, int CIN>
 int launch_fs_tn(const FsPlan &pl, hipStream_t st) {
     constexpr int W2 = CIN >= 32 ? 2 : 1;
+    if (pl.TN == 1 && pl.OCC == 2) {
+        if constexpr (CIN <= (KK == 9 ? 32 : 64)) return launch_fs<KK, CIN, 1, 1, 2>(pl, st);
+    }
     if (pl.TN == 1) return launch_fs<KK, CIN, 1, 1>(pl, st);
     if (pl.TN == 2) return launch_fs<KK, CIN, 2, W2>(pl, st);
     if (KK == 1 && pl.TN == 4) return launch_fs<1, CIN, 4, W2>(pl, st);
@@ -669,7 +697,8 @@ int launch_fs_tn(const FsPlan &pl, hipStream_t st) {
 // every supported 3x3 (64 -> 64 at 80x80: 50 / 68-74, at 40x40: 20 / 24; 32 -> 32 at 80x80: 32-34 / 32-36; 16 -> 16 at
 // 160x160: 78 / 93); pointwise layers over >= 1 M pixels (32 -> 16 at 160x160: 51 / 60) or with N >= 64 and K <= N
 // (64 -> 64 at 80x80: 24.5 / 25.0, 128 -> 128 at 40x40: 17.9 / 18.1 -- equal, and ONE BatchNorm partial row per workgroup
-// instead of one per 128 pixels); wide-K narrow-N pointwise layers stay on the gather GEMM (128 -> 32 at 80x80: 28.9 / 26.1).
+// instead of one per 128 pixels) or with N <= 32 and K <= 64 (two workgroups per CU: 64 -> 32 at 80x80 18.8 / 19.8); the 128 -> 32
+// layers stay on the gather GEMM (28.7 / 25.9).
 bool yh_bf16_fstream_supported(int B, int H, int W, int K, int N, int k, int s) {
     if (s != 1) return false;
     FsPlan pl{};
@@ -678,7 +707,7 @@ bool yh_bf16_fstream_supported(int B, int H, int W, int K, int N, int k, int s) 
 }
 bool yh_bf16_fstream_ok(int B, int H, int W, int K, int N, int k, int s) {
     if (!yh_bf16_fstream_supported(B, H, W, K, N, k, s)) return false;
-    return k == 3 || (int64_t)B * H * W >= (1 << 20) || (N >= 64 && K <= N);
+    return k == 3 || (int64_t)B * H * W >= (1 << 20) || (N >= 64 && K <= N) || (N <= 32 && K <= 64);
 }
 
 int yh_bf16_fstream_blocks(int B, int H, int W, int K, int N, int k) {

@@ -448,15 +448,14 @@ __global__ void bn_silu_bwd_reduce_kernel(const T *__restrict__ da, int ldda, co
 #pragma unroll
     for (int e = 0; e < G; ++e) { red[t * 2 * G + e] = s1[e]; red[t * 2 * G + G + e] = s2[e]; }
     __syncthreads();
-    if (t < cq) {
-        V a, b;
-#pragma unroll
-        for (int e = 0; e < G; ++e) a[e] = b[e] = 0.f;
-        for (int k = 0; k < rg; ++k)
-#pragma unroll
-            for (int e = 0; e < G; ++e) { a[e] += red[(k * cq + t) * 2 * G + e]; b[e] += red[(k * cq + t) * 2 * G + G + e]; }
-        *(V *)(part + ((size_t)blockIdx.x * 2 + 0) * C + G * t) = a;
-        *(V *)(part + ((size_t)blockIdx.x * 2 + 1) * C + G * t) = b;
+    // row groups summed in a fixed order, one COLUMN (channel, which sum) per thread: consecutive threads read consecutive
+    // floats (the first form gave this loop to C / G threads with rg * 2 G reads each: as long as the main loop at 8-channel groups)
+    const int ncol = cq * 2 * G;                 // = 2 C
+    for (int col = t; col < ncol; col += 256) {
+        float a = 0.f;
+        for (int k = 0; k < rg; ++k) a += red[k * ncol + col];
+        const int c4o = col / (2 * G), e = col - c4o * 2 * G;
+        part[((size_t)blockIdx.x * 2 + (e >= G ? 1 : 0)) * C + c4o * G + (e >= G ? e - G : e)] = a;
     }
 }
 
@@ -838,10 +837,15 @@ static int bn_silu_bwd_reduce_t(const T *da, int ldda, const T *y, int ldy, cons
     YH_REQUIRE(C <= 1024, "bn_silu_bwd_reduce: C too large");
     int nblk = yh_bn_bwd_blocks(M, C);
     int64_t rows = cdiv64(M, nblk);
-    // (8-channel groups measured SLOWER here -- 0.87 -> 1.01 ms per bf16 step: half as many row groups per workgroup and twice the
-    // sigmoid work per trip; the reduce keeps 4-channel groups for both storage types)
-    hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<T, 4>), dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
-                       da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
+    // bf16: 8-channel groups = 16-byte loads (8-byte loads top out at ~3.3 TB/s on this pass: the address path, not HBM); they
+    // measured slower in round 2 (0.87 -> 1.01 ms) because the final sum over the row groups ran on C / 8 threads -- now one
+    // column per thread
+    if (sizeof(T) == 2 && wide_groups<T>(C, {ldda, ldy}, {da, y}))
+        hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<T, 8>), dim3(nblk), dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream,
+                           da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
+    else
+        hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<T, 4>), dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
     YH_CHECK_LAUNCH("bn_silu_bwd_reduce");
     return 0;
 }
