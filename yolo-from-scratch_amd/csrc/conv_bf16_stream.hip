@@ -648,9 +648,6 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     // four-wave workgroups with one 32-column block can run TWO per CU (their phases drift apart and overlap; measured on the
     // 3x3 layers, us at one / two per CU: 32 -> 32 at 80x80 34 / 26, 16 -> 16 at 160x160 74 / 52; 64 -> 64 would need column
     // blocks of 32 and two passes over the input: 50 / 57, so it keeps the eight-wave form)
-#ifdef YH_WGS_TUNE
-    if (getenv("YH_FS_TN1") && k == 1 && K <= 64) pl.TN = 1;
-#endif
     pl.OCC = (pl.TN == 1 && K <= (k == 3 ? 32 : 64)) ? 2 : 1;
     const int BN = 32 * pl.TN;
     pl.gy = cdiv(N, BN);
@@ -665,6 +662,8 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     pl.smem = (size_t)g.R * PS + (size_t)128 * (BN * 2 + 16) + 128 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
     if (pl.smem > 160 * 1024) return;
     pl.WN = (pl.TN >= 2 && K >= 32) ? 2 : 1;                    // eight waves wherever a wave still owns a whole 32-column tile
+    // (measured and dropped: 32-column blocks at two per CU for K = 64 pointwise layers -- the input is streamed twice: 24.8 ->
+    // 26.5 us for 64 -> 64 at 80x80; four waves x 64 columns at two per CU: 24.8 -> 28.9 us)
     if (pl.KK * (K / 16) * (pl.TN / pl.WN) * 4 > 160) return;   // B fragments in registers: taps * k-steps * column tiles * 4 VGPRs
     pl.ok = true;
 }
