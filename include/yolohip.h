@@ -275,6 +275,12 @@ int yh_maxpool5_fwd(const float *x, int ldx, float *y, int ldy, uint8_t *argmax,
 /* dx += route(dy) (gather form, deterministic). */
 int yh_maxpool5_bwd(const float *dy, int lddy, const uint8_t *argmax, float *dx, int lddx, int B, int H, int W,
                     int C, void *stream);
+/* Inference form of the SPPF pooling cascade (train.py:246-248): y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) in one
+ * launch, no argmax.  One workgroup per (4 channels, image) keeps the plane in LDS: needs yh_sppf_pool3_ok(H, W)
+ * (H*W <= 4096); y1..y3 share ldy. */
+int yh_sppf_pool3_ok(int H, int W);
+int yh_sppf_pool3_fwd(const float *x, int ldx, float *y1, float *y2, float *y3, int ldy, int B, int H, int W, int C,
+                      void *stream);
 
 /* ---- loss: decode + CIoU + BCE, three scales, forward and backward in one pass ----------------- */
 /* pred[s], target[s]: (B,G_s,G_s,3,5+nc) contiguous, G_s = grid[s]; grid[s] == 0 marks an absent scale
@@ -459,7 +465,8 @@ enum {
     YH_OP_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
     YH_OP_BF16_CONV_NARROW,       /* slots of YH_OP_CONV_NARROW + i[11] = kpad (padded K rows per tap of the bf16 pack) */
     YH_OP_BF16_CONV_NARROW_DGRAD_S2,   /* slots of YH_OP_CONV_BWD_DATA + i[11] = kpad */
-    YH_OP_BF16_CONV_NARROW_BWD_WEIGHT  /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
+    YH_OP_BF16_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
+    YH_OP_SPPF_POOL3                   /* p: x, y1, y2, y3;  i: ldx, ldy, B, H, W, C */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

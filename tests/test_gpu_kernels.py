@@ -197,6 +197,29 @@ def test_maxpool5_chain_matches_torch_including_ties():
     assert rel_err(dcat[..., :C].permute(0, 3, 1, 2), x.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,H,W", [(1, 256, 20, 20), (3, 8, 11, 9), (2, 12, 64, 64), (1, 4, 3, 2)])
+def test_sppf_pool3_one_launch_matches_torch_cascade(B, C, H, W):
+    """inference form of SPPF's pooling (train.py:246-248): three cascaded pools in one launch, NaN wins like torch"""
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, H, W)
+    x[0, 0, H // 2, W // 2] = float("nan")
+    x[-1, C - 1, 0, 0] = float("inf")
+    y1 = F.max_pool2d(x, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    assert lib.yh_sppf_pool3_ok(H, W) == 1 and lib.yh_sppf_pool3_ok(65, 64) == 0
+    cat = torch.zeros(B, H, W, 4 * C, device="cuda")
+    cat[..., :C] = nhwc(x)
+    base = cat.data_ptr()
+    L.check(lib.yh_sppf_pool3_fwd(base, 4 * C, base + 4 * C, base + 8 * C, base + 12 * C, 4 * C, B, H, W, C, st))
+    ref = torch.cat([x, y1, y2, y3], 1)
+    got = cat.permute(0, 3, 1, 2).cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert torch.equal(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(ref, nan=0.0))
+    assert lib.yh_sppf_pool3_fwd(base, 4 * C, base + 4 * C, base + 8 * C, base + 12 * C, 4 * C, B, 65, 64, C, st) != 0   # too large for LDS: refused
+
+
 @pytest.mark.parametrize("n,world", [(1003, 1), (4096, 4)])
 def test_clip_adam_matches_oracle(n, world):
     from oracle import yolo_oracle as orc

@@ -37,7 +37,7 @@ class YhOp(C.Structure):
  OP_BF16_PACK_MULTI, OP_BF16_CONV_FWD, OP_BF16_CONV_BWD_DATA, OP_BF16_CONV_BWD_WEIGHT, OP_BF16_COLSUM, OP_BF16_BN_SILU_FWD,
  OP_BF16_BN_SILU_BWD_REDUCE, OP_BF16_BN_SILU_BWD_APPLY, OP_BF16_MAXPOOL5_FWD, OP_BF16_MAXPOOL5_BWD,
  OP_FOLD_OIHW_MULTI, OP_CONV_WINO_FWD_FUSED, OP_CONV_PW_FWD_FUSED, OP_CONV_NARROW, OP_CONV_NARROW_DGRAD_S2, OP_CONV_NARROW_BWD_WEIGHT, OP_BF16_CONV_NARROW, OP_BF16_CONV_NARROW_DGRAD_S2,
- OP_BF16_CONV_NARROW_BWD_WEIGHT) = range(1, 55)
+ OP_BF16_CONV_NARROW_BWD_WEIGHT, OP_SPPF_POOL3) = range(1, 56)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -104,6 +104,8 @@ _SIGS = {
                                    i64, i32, i32, i32, i32, c_fp]),
     "yh_maxpool5_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, c_fp]),
     "yh_maxpool5_bwd": (i32, [c_fp, i32, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "yh_sppf_pool3_ok": (i32, [i32, i32]),
+    "yh_sppf_pool3_fwd": (i32, [c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_yolo_loss": (i32, [_PP, _PP, _PP, C.POINTER(f32), _IP, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp, c_fp]),
     "yh_loss_ws": (i64, [_IP, i32]),
     "yh_yolo_loss_ex": (i32, [_PP, _PP, _PP, i32, _IP, C.POINTER(f32), _IP, i32, i32, f32, C.POINTER(f32), C.POINTER(f32), c_fp, c_fp,

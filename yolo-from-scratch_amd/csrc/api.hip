@@ -65,6 +65,9 @@ static int run_one(const yh_op &o, void *st) {
                                         (float *)p[7], i[3], (float *)p[8], i[4], i[5], o.l[0], i[6], i[7], i[8], i[9], st);
         case YH_OP_MAXPOOL5_FWD:
             return yh_maxpool5_fwd((const float *)p[0], i[0], (float *)p[1], i[1], (uint8_t *)p[2], i[2], i[3], i[4], i[5], st);
+        case YH_OP_SPPF_POOL3:
+            return yh_sppf_pool3_fwd((const float *)p[0], i[0], (float *)p[1], (float *)p[2], (float *)p[3], i[1], i[2], i[3], i[4],
+                                     i[5], st);
         case YH_OP_MAXPOOL5_BWD:
             return yh_maxpool5_bwd((const float *)p[0], i[0], (const uint8_t *)p[1], (float *)p[2], i[1], i[2], i[3], i[4],
                                    i[5], st);

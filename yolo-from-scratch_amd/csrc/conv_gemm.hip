@@ -626,9 +626,15 @@ SkPlan sk_plan(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
     p.tiles = (int)(((M + p.bm - 1) / p.bm) * ((Cout + p.bn - 1) / p.bn));
     p.ldws = (Cout + 3) / 4 * 4;
     const int nch = (k * k * Cin + BK - 1) / BK;
+#ifdef YH_WGS_TUNE
+    static const int target = getenv("YH_SK_TARGET") ? atoi(getenv("YH_SK_TARGET")) : 192;
+    static const int minch = getenv("YH_SK_MINCH") ? atoi(getenv("YH_SK_MINCH")) : 2;
+#else
     constexpr int target = 192;      // workgroups per layer
+    constexpr int minch = 2;         // at least two K chunks per split
+#endif
     int S = target / p.tiles;
-    if (S > nch / 2) S = nch / 2;          // at least two K chunks per split
+    if (S > nch / minch) S = nch / minch;
     if (S > 32) S = 32;
     p.splits = (M > 65536 || S < 2) ? 1 : S;
     return p;

@@ -19,8 +19,9 @@
 //      the lower candidate index first = a stable descending sort.  Boxes / classes are scattered to sorted order.
 //   2. 64x64-tiled suppression bit matrix (upper triangle): bit (i, j) = j > i, same class, IoU > thr; a fixed grid
 //      walks the blocks the device-side M needs.
-//   3. one workgroup resolves the greedy scan: per 64-box block one wave walks the (prefetched) diagonal word, then all
-//      threads OR the kept rows into the later removal words held in LDS (one (row, word) pair per thread).
+//   3. one workgroup resolves the greedy scan: per 64-box block one wave walks the (prefetched) diagonal word with a
+//      scalar chain and ORs the next two removal words itself; the other waves OR the kept rows into the later removal
+//      words held in LDS one step behind, their mask loads requested a step ahead of use.
 #pragma clang fp contract(off)
 #include "common.h"
 
@@ -150,32 +151,43 @@ struct NmsArgs {
 };
 
 // Stable descending-score order by RANK COUNTING: the keys (score, candidate index) are unique, so the position of a
-// candidate in the sorted order is the number of keys smaller than its own.  One thread per candidate walks all M keys
-// (staged through LDS, broadcast reads) -- M^2 / 2^8 compares per workgroup spread over the whole chip, ~10 us at
-// M = 3000 where a single-workgroup LDS bitonic sort took 75 us of barriers.
-__global__ __launch_bounds__(64) void nms_rank_kernel(const NmsArgs a) {
+// candidate in the sorted order is the number of keys smaller than its own.  A workgroup owns 64 candidates; its four
+// waves each walk a quarter of every LDS-staged key tile (broadcast 16-byte reads) and the four partial counts meet in
+// LDS -- M / 64 workgroups use all four SIMDs of their CU (at M = 3000 only 47 of the 256 CUs have work, so the walk per
+// SIMD is what the kernel's duration is made of).
+constexpr int kRankWaves = 4;
+__global__ __launch_bounds__(64 * kRankWaves) void nms_rank_kernel(const NmsArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t tile[kRankTile];
+    __shared__ int part[kRankWaves][64];
     int M = a.count[0];
     if (M > a.cap) M = a.cap;
-    const int i = blockIdx.x * 64 + threadIdx.x;         // one wave per workgroup: 4x the workgroups, no LDS contention inside one
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     if (blockIdx.x * 64 >= M) return;                     // whole workgroup out of range (uniform)
     const uint64_t mine = i < M ? make_key(a.scores[i], i) : ~0ull;
     int rank = 0;
     typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    constexpr int QT = kRankTile / kRankWaves;
     for (int base = 0; base < M; base += kRankTile) {
         __syncthreads();
-        for (int j = threadIdx.x; j < kRankTile; j += 64) {
+        for (int j = threadIdx.x; j < kRankTile; j += 64 * kRankWaves) {
             int c = base + j;
             tile[j] = c < M ? make_key(a.scores[c], c) : ~0ull;       // padding keys are never smaller than a real key
         }
         __syncthreads();
-        const int lim = (M - base) < kRankTile ? ((M - base + 1) & ~1) : kRankTile;
+        int lim = M - base - wave * QT;                   // keys of this wave's quarter that exist (padding counts nothing)
+        lim = lim <= 0 ? 0 : (lim < QT ? ((lim + 1) & ~1) : QT);
+        const uint64_t *q = tile + wave * QT;
 #pragma unroll 8
         for (int j = 0; j < lim; j += 2) {                // broadcast 16-byte reads: two keys per LDS instruction
-            const u64x2 k2 = *(const u64x2 *)&tile[j];
+            const u64x2 k2 = *(const u64x2 *)&q[j];
             rank += (k2[0] < mine ? 1 : 0) + (k2[1] < mine ? 1 : 0);
         }
     }
+    part[wave][lane] = rank;
+    __syncthreads();
+    if (wave != 0) return;
+    rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
     float cmax = -INFINITY;
     if (i < M) {
         a.order[rank] = i;
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(64) void nms_rank_kernel(const NmsArgs a) {
     // boxes.max() of the coordinate trick: this workgroup's share (max is exact, so any reduction order gives the same bits)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cmax = max_nan(cmax, __shfl_xor(cmax, o));
-    if (threadIdx.x == 0) a.pmax[blockIdx.x] = cmax;
+    if (lane == 0) a.pmax[blockIdx.x] = cmax;
 }
 
 // 64 x 64 blocks of the suppression bit matrix, upper triangle only (row block <= column block); a fixed grid of
@@ -257,61 +269,114 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
     }
 }
 
-// Greedy scan in descending score order, 64 candidates per step.  The removal words live in LDS.  Per step: wave 0
-// resolves the block against its own (prefetched) diagonal word with a scalar chain, then ALL threads OR the mask rows
-// of the newly kept candidates into the later removal words -- one (kept row, word) pair per thread, LDS atomic OR (order
-// independent, so the result is deterministic); the serial part of a step is the 64-long chain only.
+// Greedy scan in descending score order, 64 candidates per step, one workgroup.  The removal words live in LDS.
+//
+// What a step waits for is kept short: wave 0 resolves block bi against its diagonal word with a SCALAR chain (the
+// removal word sits in an SGPR pair: bit test, select, or -- three dependent scalar instructions per candidate; a kept
+// candidate's own bit is never set later, so kept = ~removal at the end of the chain), then ORs the kept rows' words
+// bi+1 and bi+2 (fetched with the diagonal, one step ahead) across the wave into LDS itself.  Every later word is the
+// other fifteen waves' job, one step behind: during step bi they request the mask rows of the candidates kept in step
+// bi-1 (words >= bi+2) and OR in what they requested during step bi-1, so no step waits for a global load and block
+// bi+2 still finds its removal word complete.  LDS ORs are atomic and order independent: the result is deterministic.
 __global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) {
     __shared__ uint64_t remv[kMaxWords];
-    __shared__ int klist[64];
-    __shared__ int nkept_sh, nk_sh;
+    __shared__ int klist[2][64];
+    __shared__ int nkept_sh[2];
     int M = a.count[0];
     if (M > a.cap) M = a.cap;
     const int nw = (M + 63) >> 6;
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int w = t; w < nw; w += kNmsThreads) remv[w] = (w == nw - 1 && (M & 63)) ? ~0ull << (M & 63) : 0ull;   // boxes past M never win
-    if (t == 0) nk_sh = 0;
-    uint64_t diag_next = 0;
-    if (t < 64 && nw > 0) diag_next = lane < M ? a.mask[(size_t)lane * a.W] : 0ull;
+    constexpr int NH = kNmsThreads - 64, NP = 4;      // helper threads, requests a helper keeps in flight
+    uint64_t pv[NP];
+    int pw[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { pv[q] = 0ull; pw[q] = 0; }
+    auto lds_or = [&](int w, uint64_t v) {
+        unsigned *r32 = (unsigned *)&remv[w];
+        if ((unsigned)v) atomicOr(r32, (unsigned)v);
+        if ((unsigned)(v >> 32)) atomicOr(r32 + 1, (unsigned)(v >> 32));
+    };
+    uint64_t nx0 = 0, nx1 = 0, nx2 = 0;               // wave 0: next block's diagonal word and the two words after it
+    int nxo = 0;                                      //         and its candidates' original indices
+    auto fetch3 = [&](int b) {
+        const int r = b * 64 + lane;
+        const uint64_t *row = a.mask + (size_t)r * a.W + b;
+        nx0 = r < M ? row[0] : 0ull;
+        nx1 = (r < M && b + 1 < nw) ? row[1] : 0ull;
+        nx2 = (r < M && b + 2 < nw) ? row[2] : 0ull;
+        nxo = r < M ? a.order[r] : 0;
+    };
+    int nk = 0;
+    if (wave == 0 && nw > 0) fetch3(0);
     __syncthreads();
     for (int bi = 0; bi < nw; ++bi) {
-        if (t < 64) {
-            const uint64_t diag = diag_next;
-            if (bi + 1 < nw) {                     // the next block's diagonal word does not depend on this block's outcome
-                const int r = (bi + 1) * 64 + lane;
-                diag_next = r < M ? a.mask[(size_t)r * a.W + bi + 1] : 0ull;
-            }
-            uint64_t cur = remv[bi], kept = 0;
-            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        if (wave == 0) {
+            const uint64_t dg = nx0, d1 = nx1, d2 = nx2;
+            const int ord = nxo;                      // nothing in a step waits for a load issued in the same step
+            if (bi + 1 < nw) fetch3(bi + 1);          // does not depend on this block's outcome
+            const uint64_t r0 = remv[bi];
+            uint64_t cur = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r0 >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r0);
+            const unsigned dlo = (unsigned)dg, dhi = (unsigned)(dg >> 32);
 #pragma unroll
             for (int b = 0; b < 64; ++b) {
                 const uint64_t d = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
                                    (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-                if (!((cur >> b) & 1ull)) { kept |= 1ull << b; cur |= d; }
+                uint64_t sel;                          // cur |= bit b of cur set ? 0 : d
+                asm("s_bitcmp1_b64 %0, %2\n\ts_cselect_b64 %1, 0, %3\n\ts_or_b64 %0, %0, %1"
+                    : "+s"(cur), "=&s"(sel) : "n"(b), "s"(d) : "scc");
             }
-            const int base = nk_sh;
-            if ((kept >> lane) & 1ull) {
+            const uint64_t kept = ~cur;
+            const bool mine = (kept >> lane) & 1ull;
+            if (mine) {
                 const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-                a.keep[base + pos] = a.order[bi * 64 + lane];
-                klist[pos] = lane;
+                a.keep[nk + pos] = ord;
+                klist[bi & 1][pos] = lane;
             }
-            if (lane == 0) { nkept_sh = __popcll(kept); nk_sh = base + __popcll(kept); }
-        }
-        __syncthreads();
-        const int nkept = nkept_sh, nrem = nw - bi - 1;
-        const int total = nkept * nrem;
-        for (int idx = t; idx < total; idx += kNmsThreads) {
-            const int kb = idx / nrem, w = bi + 1 + (idx - kb * nrem);
-            const uint64_t v = a.mask[(size_t)(bi * 64 + klist[kb]) * a.W + w];
-            if (v) {
-                unsigned *r32 = (unsigned *)&remv[w];
-                if ((unsigned)v) atomicOr(r32, (unsigned)v);
-                if ((unsigned)(v >> 32)) atomicOr(r32 + 1, (unsigned)(v >> 32));
+            if (lane == 0) nkept_sh[bi & 1] = __popcll(kept);
+            nk += __popcll(kept);
+            unsigned o0 = mine ? (unsigned)d1 : 0u, o1 = mine ? (unsigned)(d1 >> 32) : 0u;
+            unsigned o2 = mine ? (unsigned)d2 : 0u, o3 = mine ? (unsigned)(d2 >> 32) : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                o0 |= __shfl_xor(o0, o); o1 |= __shfl_xor(o1, o);
+                o2 |= __shfl_xor(o2, o); o3 |= __shfl_xor(o3, o);
+            }
+            if (lane == 0) {
+                if (bi + 1 < nw) lds_or(bi + 1, ((uint64_t)o1 << 32) | o0);
+                if (bi + 2 < nw) lds_or(bi + 2, ((uint64_t)o3 << 32) | o2);
+            }
+        } else {
+            const int ht = t - 64;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if (pv[q]) lds_or(pw[q], pv[q]);     // requested one step ago
+#pragma unroll
+            for (int q = 0; q < NP; ++q) pv[q] = 0ull;
+            const int w0 = bi + 2, nrem = nw - w0;    // rows kept in step bi-1, words >= (bi-1) + 3
+            if (bi >= 1 && nrem > 0) {
+                const int src = (bi - 1) & 1, total = nkept_sh[src] * nrem;
+                const uint64_t *rows = a.mask + (size_t)(bi - 1) * 64 * a.W;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int idx = ht + q * NH;
+                    if (idx < total) {
+                        const int kb = idx / nrem, w = w0 + (idx - kb * nrem);
+                        pv[q] = rows[(size_t)klist[src][kb] * a.W + w];
+                        pw[q] = w;
+                    }
+                }
+                for (int idx = ht + NP * NH; idx < total; idx += NH) {      // more pairs than request slots (cap > 3900): right away
+                    const int kb = idx / nrem, w = w0 + (idx - kb * nrem);
+                    const uint64_t v = rows[(size_t)klist[src][kb] * a.W + w];
+                    if (v) lds_or(w, v);
+                }
             }
         }
         __syncthreads();
     }
-    if (t == 0) a.nkeep[0] = nk_sh;
+    if (t == 0) a.nkeep[0] = nk;
 }
 
 // Kept detections as one dense table: header {count, nkeep} + nkeep rows (x1, y1, x2, y2, score, class bits) in NMS order,
@@ -461,7 +526,7 @@ extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *cl
     a.pmax = (float *)p;      p += align_up((size_t)a.W * 4, 256);
     a.mask = (uint64_t *)p;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(cap, 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(cdiv(cap, 64)), dim3(64 * kRankWaves), 0, st, a);
     YH_CHECK_LAUNCH("nms_rank");
     const int64_t pairs = (int64_t)a.W * (a.W + 1) / 2;
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)(pairs < 2048 ? pairs : 2048)), dim3(64), 0, st, a);

@@ -931,6 +931,64 @@ extern "C" int yh_bf16_maxpool5_bwd(const void *dy, int lddy, const uint8_t *arg
     return maxpool5_bwd_t<bf16>((const bf16 *)dy, lddy, argmax, (bf16 *)dx, lddx, B, H, W, C, stream);
 }
 
+// ---- inference SPPF: the three cascaded 5x5 pools of one image in ONE launch ---------------------------------------------
+// y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) (train.py:246-248).  A workgroup owns four channels of one image and keeps
+// the whole H x W plane in LDS (two planes of float4): each stage is a 5-tap row maximum followed by a 5-tap column maximum
+// (the 5x5 window maximum is separable; NaN wins like torch's max_pool2d), written to the stage's output and left in LDS as
+// the next stage's input.  At batch 1 the three launches of the training kernel were 12 us each for a 400-pixel plane.
+__device__ __forceinline__ f32x4 nan_max4(f32x4 a, f32x4 b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (b[e] > a[e] || b[e] != b[e]) a[e] = b[e];
+    return a;
+}
+
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y1,
+                                                         float *__restrict__ y2, float *__restrict__ y3, int ldy, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float pool_smem[];
+    f32x4 *P = (f32x4 *)pool_smem, *Q = P + H * W;
+    const int c = blockIdx.x * 4, HW = H * W;
+    const size_t img = (size_t)blockIdx.y * HW;
+    for (int p = threadIdx.x; p < HW; p += 256) P[p] = ld4(x + (img + p) * ldx + c);
+    __syncthreads();
+    float *const outs[3] = {y1, y2, y3};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int h = p / W, w = p - h * W;
+            const int lo = w < 2 ? -w : -2, hi = w + 2 >= W ? W - 1 - w : 2;
+            f32x4 m = P[p + lo];
+            for (int d = lo + 1; d <= hi; ++d) m = nan_max4(m, P[p + d]);
+            Q[p] = m;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int h = p / W;
+            const int lo = h < 2 ? -h : -2, hi = h + 2 >= H ? H - 1 - h : 2;
+            f32x4 m = Q[p + lo * W];
+            for (int d = lo + 1; d <= hi; ++d) m = nan_max4(m, Q[p + d * W]);
+            P[p] = m;
+            st4(outs[s] + (img + p) * ldy + c, m);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int yh_sppf_pool3_ok(int H, int W) { return H > 0 && W > 0 && (int64_t)H * W <= 4096; }
+
+extern "C" int yh_sppf_pool3_fwd(const float *x, int ldx, float *y1, float *y2, float *y3, int ldy, int B, int H, int W, int C,
+                                 void *stream) {
+    YH_REQUIRE(x && y1 && y2 && y3 && B > 0 && B < 65536, "sppf_pool3_fwd: bad argument");
+    YH_REQUIRE(yh_sppf_pool3_ok(H, W), "sppf_pool3_fwd: a %d x %d plane does not fit the LDS form (H*W <= 4096); use yh_maxpool5_fwd", H, W);
+    YH_REQ_VEC4("sppf_pool3_fwd", C, ldx, ldy);
+    YH_REQUIRE((((uintptr_t)y1 | (uintptr_t)y2 | (uintptr_t)y3) & 15) == 0, "sppf_pool3_fwd: outputs must be 16-byte aligned");
+    const size_t smem = (size_t)2 * H * W * 16;
+    if (int rc = yh_ensure_dyn_smem((const void *)sppf_pool3_kernel, smem)) return rc;
+    hipLaunchKernelGGL(sppf_pool3_kernel, dim3(C / 4, B), dim3(256), smem, (hipStream_t)stream, x, ldx, y1, y2, y3, ldy, H, W);
+    YH_CHECK_LAUNCH("sppf_pool3_fwd");
+    return 0;
+}
+
 extern "C" int yh_add_int64(int64_t *p, int64_t v, void *stream) {
     YH_REQUIRE(p, "add_int64: null pointer");
     hipLaunchKernelGGL(add_int64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);

@@ -99,6 +99,10 @@ class View:
     def gptr(self) -> int: return self.buf.grad.data_ptr() + self.buf.grad.element_size() * self.off
 
 
+def _same_view(a: "View", b: "View") -> bool:
+    return a.buf is b.buf and a.off == b.off and a.C == b.C
+
+
 @dataclass
 class ConvRec:
     """conv (+bias) [+ BatchNorm + SiLU (+residual) (+x2 upsample on write)]"""
@@ -149,6 +153,7 @@ class PoolRec:
     out: View
     arg: Optional[torch.Tensor] = None
     lane: int = 0
+    fused: bool = False     # eval: computed by the preceding pool's three-stage launch
 
 
 @dataclass
@@ -488,6 +493,19 @@ class Plan:
                                    i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
                                       int(r.upsample)], l=[M], lane=ln))
             else:
+                if r.fused:
+                    continue
+                if not self.training and lib.yh_sppf_pool3_ok(r.x.H, r.x.W):
+                    # eval: SPPF's cascade pool5(pool5(pool5(x))) as one launch (no argmax, the plane stays in LDS)
+                    nxt = self.recs[ri + 1: ri + 3]
+                    if len(nxt) == 2 and all(isinstance(q, PoolRec) and q.lane == ln for q in nxt) \
+                            and _same_view(nxt[0].x, r.out) and _same_view(nxt[1].x, nxt[0].out) \
+                            and r.out.ld == nxt[0].out.ld == nxt[1].out.ld \
+                            and all(v.ptr() % 16 == 0 for v in (r.out, nxt[0].out, nxt[1].out)):
+                        fwd.append(_op(L.OP_SPPF_POOL3, p=[r.x.ptr(), r.out.ptr(), nxt[0].out.ptr(), nxt[1].out.ptr()],
+                                       i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C], lane=ln))
+                        nxt[0].fused = nxt[1].fused = True
+                        continue
                 r.arg = torch.empty(r.x.B, r.x.H, r.x.W, r.x.C, device=dev, dtype=torch.uint8)
                 fwd.append(_op(L.OP_MAXPOOL5_FWD, p=[r.x.ptr(), r.out.ptr(), r.arg],
                                i=[r.x.ld, r.out.ld, r.x.B, r.x.H, r.x.W, r.x.C], lane=ln))
