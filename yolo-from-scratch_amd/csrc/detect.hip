@@ -19,9 +19,9 @@
 //      the lower candidate index first = a stable descending sort.  Boxes / classes are scattered to sorted order.
 //   2. 64x64-tiled suppression bit matrix (upper triangle): bit (i, j) = j > i, same class, IoU > thr; a fixed grid
 //      walks the blocks the device-side M needs.
-//   3. one workgroup resolves the greedy scan: per 64-box block one wave walks the (prefetched) diagonal word with a
-//      scalar chain and ORs the next two removal words itself; the other waves OR the kept rows into the later removal
-//      words held in LDS one step behind, their mask loads requested a step ahead of use.
+//   3. one workgroup resolves the greedy scan: per 64-box block one wave walks the diagonal word with a scalar chain and
+//      ORs the next removal word itself; the other waves stage the diagonal band through LDS and OR the kept rows into
+//      the later removal words, every mask load requested several steps ahead of its use.
 #pragma clang fp contract(off)
 #include "common.h"
 
@@ -59,15 +59,22 @@ __global__ void cand_count_kernel(const CandArgs a) {
     if (threadIdx.x == 0) a.blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ void cand_scan_kernel(const CandArgs a) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int run = 0;
-        for (int b = 0; b < a.nblk; ++b) {
-            a.blk[a.nblk + b] = run;
-            run += a.blk[b];
+__global__ __launch_bounds__(64) void cand_scan_kernel(const CandArgs a) {      // one wave: exclusive prefix of the block counts
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int b0 = 0; b0 < a.nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const int c = b < a.nblk ? a.blk[b] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
         }
-        a.count[0] = run;
+        if (b < a.nblk) a.blk[a.nblk + b] = run + inc - c;
+        run += __shfl(inc, 63);
     }
+    if (lane == 0) a.count[0] = run;
 }
 
 __global__ void cand_write_kernel(const CandArgs a) {
@@ -269,52 +276,64 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
     }
 }
 
-// Greedy scan in descending score order, 64 candidates per step, one workgroup.  The removal words live in LDS.
+// Greedy scan in descending score order, 64 candidates per step, one workgroup of 16 waves with fixed roles.  The removal
+// words live in LDS.  The mask was written by other CUs a moment ago, so every read of it is a ~2 us trip past this XCD's
+// L2: no step may wait for a load issued less than a few steps earlier.
 //
-// What a step waits for is kept short: wave 0 resolves block bi against its diagonal word with a SCALAR chain (the
-// removal word sits in an SGPR pair: bit test, select, or -- three dependent scalar instructions per candidate; a kept
-// candidate's own bit is never set later, so kept = ~removal at the end of the chain), then ORs the kept rows' words
-// bi+1 and bi+2 (fetched with the diagonal, one step ahead) across the wave into LDS itself.  Every later word is the
-// other fifteen waves' job, one step behind: during step bi they request the mask rows of the candidates kept in step
-// bi-1 (words >= bi+2) and OR in what they requested during step bi-1, so no step waits for a global load and block
-// bi+2 still finds its removal word complete.  LDS ORs are atomic and order independent: the result is deterministic.
+//   wave 0       resolves block bi: diagonal word from the LDS band ring, then a SCALAR chain (the removal word sits in an
+//                SGPR pair: bit test, select, or -- three dependent scalar instructions per candidate; a kept candidate's own
+//                bit is never set later, so kept = ~removal when the chain ends), publishes the kept list, and ORs the kept
+//                rows' word bi+1 (also in the band ring) across the wave with DPP rotations -- the only removal word the
+//                next step needs from this one.
+//   waves 1-4    band loaders: the diagonal word, the four words after it and the original index of every row of a block
+//                go into a four-slot LDS ring; a loader owns every fourth block and holds its loads four steps in registers.
+//   wave 5       ORs the kept rows' words bi+2..bi+4 out of the band ring one step later (LDS to LDS).
+//   waves 6-14   three groups taking turns: the group whose turn it is requests the kept rows' words >= bi+5 from memory
+//                and ORs in what it requested three steps ago -- block bi+5 still finds its removal word complete.
+// LDS ORs are atomic and order independent: the result is deterministic.
+constexpr int kBandWords = 5, kBandRing = 4, kFarSlots = 6, kFarThreads = 192;   // 16 waves: 128 VGPRs per lane, no spills
+
+__device__ __forceinline__ unsigned wave_or(unsigned v) {          // OR over the 64 lanes (all active), uniform result
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);    // row_ror:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);    // row_ror:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);    // row_ror:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);    // row_ror:1 -> every lane holds its row's OR
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 __global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) {
+    static_assert(kNmsThreads == 1024, "sixteen waves with fixed roles");
     __shared__ uint64_t remv[kMaxWords];
+    __shared__ uint64_t band[kBandRing][kBandWords][64];
+    __shared__ int bord[kBandRing][64];
     __shared__ int klist[2][64];
     __shared__ int nkept_sh[2];
     int M = a.count[0];
     if (M > a.cap) M = a.cap;
     const int nw = (M + 63) >> 6;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     for (int w = t; w < nw; w += kNmsThreads) remv[w] = (w == nw - 1 && (M & 63)) ? ~0ull << (M & 63) : 0ull;   // boxes past M never win
-    constexpr int NH = kNmsThreads - 64, NP = 4;      // helper threads, requests a helper keeps in flight
-    uint64_t pv[NP];
-    int pw[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) { pv[q] = 0ull; pw[q] = 0; }
+    if (nw == 0) {
+        if (t == 0) a.nkeep[0] = 0;
+        return;
+    }
     auto lds_or = [&](int w, uint64_t v) {
         unsigned *r32 = (unsigned *)&remv[w];
         if ((unsigned)v) atomicOr(r32, (unsigned)v);
         if ((unsigned)(v >> 32)) atomicOr(r32 + 1, (unsigned)(v >> 32));
     };
-    uint64_t nx0 = 0, nx1 = 0, nx2 = 0;               // wave 0: next block's diagonal word and the two words after it
-    int nxo = 0;                                      //         and its candidates' original indices
-    auto fetch3 = [&](int b) {
-        const int r = b * 64 + lane;
-        const uint64_t *row = a.mask + (size_t)r * a.W + b;
-        nx0 = r < M ? row[0] : 0ull;
-        nx1 = (r < M && b + 1 < nw) ? row[1] : 0ull;
-        nx2 = (r < M && b + 2 < nw) ? row[2] : 0ull;
-        nxo = r < M ? a.order[r] : 0;
-    };
-    int nk = 0;
-    if (wave == 0 && nw > 0) fetch3(0);
-    __syncthreads();
-    for (int bi = 0; bi < nw; ++bi) {
-        if (wave == 0) {
-            const uint64_t dg = nx0, d1 = nx1, d2 = nx2;
-            const int ord = nxo;                      // nothing in a step waits for a load issued in the same step
-            if (bi + 1 < nw) fetch3(bi + 1);          // does not depend on this block's outcome
+    // Every role runs its own loop of exactly nw steps with one barrier per step (the roles are wave-uniform), so the
+    // registers a role keeps across steps -- loads in flight -- are its own.
+
+    if (wave == 0) {
+        // ---- resolver ----
+        int nk = 0;
+        __syncthreads();
+        for (int bi = 0; bi < nw; ++bi) {
+            const int slot = bi & (kBandRing - 1);
+            const uint64_t dg = band[slot][0][lane], d1 = band[slot][1][lane];
+            const int ord = bord[slot][lane];
             const uint64_t r0 = remv[bi];
             uint64_t cur = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r0 >> 32)) << 32) |
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r0);
@@ -329,54 +348,112 @@ __global__ __launch_bounds__(kNmsThreads) void nms_scan_kernel(const NmsArgs a) 
             }
             const uint64_t kept = ~cur;
             const bool mine = (kept >> lane) & 1ull;
+            const unsigned o0 = wave_or(mine ? (unsigned)d1 : 0u), o1 = wave_or(mine ? (unsigned)(d1 >> 32) : 0u);
+            if (lane == 0) {
+                if (bi + 1 < nw) lds_or(bi + 1, ((uint64_t)o1 << 32) | o0);
+                nkept_sh[bi & 1] = __popcll(kept);
+            }
             if (mine) {
                 const int pos = __popcll(kept & ((1ull << lane) - 1ull));
                 a.keep[nk + pos] = ord;
                 klist[bi & 1][pos] = lane;
             }
-            if (lane == 0) nkept_sh[bi & 1] = __popcll(kept);
             nk += __popcll(kept);
-            unsigned o0 = mine ? (unsigned)d1 : 0u, o1 = mine ? (unsigned)(d1 >> 32) : 0u;
-            unsigned o2 = mine ? (unsigned)d2 : 0u, o3 = mine ? (unsigned)(d2 >> 32) : 0u;
+            __syncthreads();
+        }
+        if (lane == 0) a.nkeep[0] = nk;
+    } else if (wave <= kBandRing) {
+        // ---- band loader: blocks j0, j0 + 4, ...; loads are unconditional (clamped addresses) and validity is applied when
+        // the registers go to LDS, so a load's destination is the register that waits four steps
+        const int j0 = wave - 1;
+        uint64_t hb[kBandWords];
+        int ho;
+        auto band_fetch = [&](int b) {
+            const int bc = b < nw ? b : nw - 1;
+            int r = bc * 64 + lane;
+            r = r < M ? r : M - 1;
+            const uint64_t *row = a.mask + (size_t)r * a.W;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                o0 |= __shfl_xor(o0, o); o1 |= __shfl_xor(o1, o);
-                o2 |= __shfl_xor(o2, o); o3 |= __shfl_xor(o3, o);
+            for (int k = 0; k < kBandWords; ++k) hb[k] = row[bc + k < nw ? bc + k : nw - 1];
+            ho = a.order[r];
+        };
+        auto band_store = [&](int b) {
+            const bool rv = b * 64 + lane < M;
+#pragma unroll
+            for (int k = 0; k < kBandWords; ++k) band[b & (kBandRing - 1)][k][lane] = (rv && b + k < nw) ? hb[k] : 0ull;
+            bord[b & (kBandRing - 1)][lane] = ho;
+        };
+        band_fetch(j0);
+        if (j0 < nw) band_store(j0);
+        band_fetch(j0 + kBandRing);
+        __syncthreads();
+        for (int bi = 0; bi < nw; ++bi) {
+            const int b = bi + 1;                     // the block the next step resolves
+            if (b >= kBandRing && ((b - j0) & (kBandRing - 1)) == 0) {
+                if (b < nw) band_store(b);            // requested four steps ago
+                band_fetch(b + kBandRing);
             }
-            if (lane == 0) {
-                if (bi + 1 < nw) lds_or(bi + 1, ((uint64_t)o1 << 32) | o0);
-                if (bi + 2 < nw) lds_or(bi + 2, ((uint64_t)o3 << 32) | o2);
+            __syncthreads();
+        }
+    } else if (wave == 5) {
+        // ---- near helper: rows kept in step bi-1, band words 2..4 -> removal words bi+1..bi+3
+        __syncthreads();
+        for (int bi = 0; bi < nw; ++bi) {
+            if (bi >= 1) {
+                const int b = bi - 1, src = b & 1, slot = b & (kBandRing - 1), total = nkept_sh[src] * 3;
+                for (int idx = lane; idx < total; idx += 64) {
+                    const int kb = idx / 3, k = 2 + (idx - 3 * kb), w = b + k;
+                    if (w < nw) {
+                        const uint64_t v = band[slot][k][klist[src][kb]];
+                        if (v) lds_or(w, v);
+                    }
+                }
             }
-        } else {
-            const int ht = t - 64;
+            __syncthreads();
+        }
+    } else if (wave < 15) {
+        // ---- far helpers: group g takes the blocks b = g, g + 3, ...; at step b + 1 it ORs in what it requested at step
+        // b - 2 (rows kept in step b - 3) and requests the rows kept in step b, words >= b + 5
+        const int fgroup = (wave - 6) / 3;
+        const int ft = (wave - 6 - 3 * fgroup) * 64 + lane;
+        uint64_t pv[kFarSlots];
+        int pw[kFarSlots];
+        int pn = 0;                                   // this thread's valid requests
 #pragma unroll
-            for (int q = 0; q < NP; ++q)
-                if (pv[q]) lds_or(pw[q], pv[q]);     // requested one step ago
+        for (int q = 0; q < kFarSlots; ++q) { pv[q] = 0ull; pw[q] = 0; }
+        __syncthreads();
+        for (int bi = 0; bi < nw; ++bi) {
+            if (bi >= 1 && (bi - 1) % 3 == fgroup) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) pv[q] = 0ull;
-            const int w0 = bi + 2, nrem = nw - w0;    // rows kept in step bi-1, words >= (bi-1) + 3
-            if (bi >= 1 && nrem > 0) {
-                const int src = (bi - 1) & 1, total = nkept_sh[src] * nrem;
-                const uint64_t *rows = a.mask + (size_t)(bi - 1) * 64 * a.W;
+                for (int q = 0; q < kFarSlots; ++q)
+                    if (q < pn && pv[q]) lds_or(pw[q], pv[q]);
+                pn = 0;
+                const int b = bi - 1, w0 = b + kBandWords, nrem = nw - w0;
+                const int src = b & 1, total = nrem > 0 ? nkept_sh[src] * nrem : 0;
+                if (ft < total) {
+                    const uint64_t *rows = a.mask + (size_t)b * 64 * a.W;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const int idx = ht + q * NH;
-                    if (idx < total) {
+                    for (int q = 0; q < kFarSlots; ++q) {
+                        int idx = ft + q * kFarThreads;
+                        if (idx < total) pn = q + 1;
+                        idx = idx < total ? idx : total - 1;             // unconditional load, clamped
                         const int kb = idx / nrem, w = w0 + (idx - kb * nrem);
                         pv[q] = rows[(size_t)klist[src][kb] * a.W + w];
                         pw[q] = w;
                     }
-                }
-                for (int idx = ht + NP * NH; idx < total; idx += NH) {      // more pairs than request slots (cap > 3900): right away
-                    const int kb = idx / nrem, w = w0 + (idx - kb * nrem);
-                    const uint64_t v = rows[(size_t)klist[src][kb] * a.W + w];
-                    if (v) lds_or(w, v);
+                    for (int idx = ft + kFarSlots * kFarThreads; idx < total; idx += kFarThreads) {   // beyond the slots: right away
+                        const int kb = idx / nrem, w = w0 + (idx - kb * nrem);
+                        const uint64_t v = rows[(size_t)klist[src][kb] * a.W + w];
+                        if (v) lds_or(w, v);
+                    }
                 }
             }
+            __syncthreads();
         }
+    } else {
         __syncthreads();
+        for (int bi = 0; bi < nw; ++bi) __syncthreads();
     }
-    if (t == 0) a.nkeep[0] = nk;
 }
 
 // Kept detections as one dense table: header {count, nkeep} + nkeep rows (x1, y1, x2, y2, score, class bits) in NMS order,
