@@ -16,6 +16,12 @@
 // Slabs are written in the layout of bf16_wgrad_reduce_kernel (conv_bf16.hip), whose fixed-order sum gives the OIHW fp32
 // gradient: bitwise reproducible.
 #include "bf16_common.h"
+#include <type_traits>
+#ifdef YH_FS_STAMPS
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -383,6 +389,9 @@ struct FsP {
     int ntile, tiles_per_wg, gx, gy;
     int R, halo;               // ring slots; XW + 1 (3x3) or 0 (1x1)
     int tapoff[9], tapw[9];
+#ifdef YH_FS_STAMPS
+    unsigned long long *dbg;   // diagnostic build: per-workgroup phase cycle sums
+#endif
 };
 
 template <int KK>
@@ -408,14 +417,15 @@ __global__ __launch_bounds__(256 * WN, WN * OCC) void bf16_fstream_kernel(const 
     constexpr int BM = 128, BN = 32 * TN, C8 = CIN / 8, KS = CIN / 16, PS = CIN * 2 + 16, PD = 4;
     constexpr int NTH = 256 * WN, TW = TN / WN;  // threads; column tiles per wave
     constexpr int NP = (BM * C8) / NTH;          // 16-byte pieces per thread and tile
-    constexpr int CS = BN * 2 + 16;              // bytes per row of the epilogue staging tile
-    constexpr int PC = BN / 8;                   // 16-byte pieces per output row
-    static_assert(NP >= 1 && (BM * C8) % NTH == 0 && TN % WN == 0 && (BM * PC) % NTH == 0, "tile shape");
+    constexpr int NW = 4 * WN;                   // waves
+    constexpr int CSW = 64 * TW + 16;            // bytes per row of a wave's private staging tile (32 rows x 32 TW columns)
+    constexpr int PCW = 4 * TW;                  // 16-byte pieces per row of it
+    static_assert(NP >= 1 && (BM * C8) % NTH == 0 && TN % WN == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *As = smem;                                  // [R][PS]
-    unsigned char *Cs = As + g.R * PS;                         // [BM][CS]
-    int *rowpix = (int *)(Cs + BM * CS);                       // [BM] output pixel of each tile row, -1 = padding position
-    float *red = (float *)(rowpix + BM);                       // [4][BN][2]
+    unsigned char *Cs = As + g.R * PS;                         // [NW][32][CSW]
+    int *rowpix = (int *)(Cs + NW * 32 * CSW);                 // [NW][32] output pixel of each of the wave's rows, -1 = padding position
+    float *red = (float *)(rowpix + NW * 32);                  // [4][BN][2]
     const int t = threadIdx.x, lane = t & 63, wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wave = wave_all & 3, cbw = 32 * TW * (wave_all >> 2);      // row group; first column of this wave's tiles
     const int lr = lane & 31, lh = lane >> 5;
@@ -534,22 +544,32 @@ __global__ __launch_bounds__(256 * WN, WN * OCC) void bf16_fstream_kernel(const 
         const int n = n0 + cbw + 32 * j + lr;
         bias_v[j] = (g.bias && n < g.N) ? g.bias[n] : 0.f;
     }
+#ifdef YH_FS_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tk = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#define FS_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - tk; tk = now_; } while (0)
+#else
+#define FS_STAMP(i) do { } while (0)
+#endif
+    // The epilogue of a wave touches only that wave's LDS (its 32 row pixels, its 32 x 32 TW staging tile): no barrier, so the
+    // waves of a workgroup are coupled by the ONE barrier per tile that publishes the ring.
+    int *const rpw = rowpix + 32 * wave_all;
+    unsigned char *const csw = Cs + wave_all * 32 * CSW;
     auto epilogue = [&](int n) __attribute__((always_inline)) {
-        if (t < BM) {
+        if (lane < 32) {
             int px;
-            rowpix[t] = fs_pixel<KK>(g, BM * n + t, px) ? px : -1;
+            rpw[lane] = fs_pixel<KK>(g, BM * n + 32 * wave + lane, px) ? px : -1;
         }
-        __syncthreads();                                   // rowpix visible; every wave is past the previous tile's stores from Cs
         float rv[16];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const i32x4 p4 = *(const i32x4 *)(rowpix + 32 * wave + 8 * q4 + 4 * lh);
+            const i32x4 p4 = *(const i32x4 *)(rpw + 8 * q4 + 4 * lh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) rv[4 * q4 + e] = p4[e] >= 0 ? 1.f : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            unsigned char *row = Cs + (32 * wave + yh_mfma_row(q, lh)) * CS + (cbw + lr) * 2;
+            unsigned char *row = csw + yh_mfma_row(q, lh) * CSW + lr * 2;
 #pragma unroll
             for (int j = 0; j < TW; ++j) {
                 const bf16 hv = (bf16)(acc[j][q] + bias_v[j]);
@@ -559,13 +579,12 @@ __global__ __launch_bounds__(256 * WN, WN * OCC) void bf16_fstream_kernel(const 
                 csq[j] += vq * (float)hv;
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < (BM * PC) / NTH; ++i) {
-            const int e = t + NTH * i, rl = e / PC, oc = e % PC;
-            const int px = rowpix[rl], nn = n0 + 8 * oc;
+        for (int i = 0; i < (32 * PCW) / 64; ++i) {
+            const int e = lane + 64 * i, rl = e / PCW, oc = e % PCW;
+            const int px = rpw[rl], nn = n0 + cbw + 8 * oc;
             if (px >= 0 && nn < g.N) {
-                bf16x8 v = *(const bf16x8 *)(Cs + rl * CS + oc * 16);
+                bf16x8 v = *(const bf16x8 *)(csw + rl * CSW + oc * 16);
                 bf16 *o = g.out + (size_t)px * g.ldo + nn;
                 if (g.accumulate) {
                     const bf16x8 old = *(const bf16x8 *)o;
@@ -575,10 +594,14 @@ __global__ __launch_bounds__(256 * WN, WN * OCC) void bf16_fstream_kernel(const 
                 *(bf16x8 *)o = v;
             }
         }
+        FS_STAMP(4);
     };
 
     // ---- pipeline (same shape as the weight-gradient stream): iteration n stores the new positions of tile n + 1, requests
     // those of tile n + PD, multiplies tile n; the first `warm` iterations only fill the ring ---------------------------------
+    // (Tried and dropped: letting the second wave group of an eight-wave workgroup write tile n - 1 out under the first group's
+    // MFMAs of tile n -- two copies of the loop, or one copy with a run-time order, cost 25+ registers and spilled at the 256
+    // the 144 B-fragment registers leave: 64 -> 64 3x3 at 80x80 50 -> 70 us.)
 #pragma unroll
     for (int p = 0; p < PD - 1; ++p) issue(nfirst - (PD - 1) + p, ra[p], mk[p]);
     for (int n = nfirst; n < T1; n += PD) {
@@ -588,14 +611,24 @@ __global__ __launch_bounds__(256 * WN, WN * OCC) void bf16_fstream_kernel(const 
                 issue(n + p, ra[(p + PD - 1) % PD], mk[(p + PD - 1) % PD]);
                 store(ra[p], mk[p]);
                 __syncthreads();
+                FS_STAMP(0);
                 if (n + p >= T0) {
                     compute();
+                    FS_STAMP(1);
                     epilogue(n + p);
                 }
                 advance();
             }
         }
     }
+#ifdef YH_FS_STAMPS
+    if (g.dbg && t == 0) {
+        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 5; ++i) d[i] = ph[i];
+        d[5] = (unsigned long long)(T1 - T0);
+        d[6] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
     if (g.stats) {
         __syncthreads();
 #pragma unroll
@@ -641,7 +674,8 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     yh_set_magic((unsigned)g.XW, g.xw_magic, g.xw_shift);
     yh_set_magic((unsigned)g.VH, g.vh_magic, g.vh_shift);
     g.halo = k == 3 ? g.XW + 1 : 0;
-    g.R = (2 * 128 + 2 * g.halo + 15) & ~15;
+    g.R = (3 * 128 + 2 * g.halo + 15) & ~15;                      // one tile more than the taps span: a wave may store the next
+                                                                // tile's positions while another still multiplies (one barrier per tile)
     // column block: all of N up to 128 columns (k = 1) / 64 columns (k = 3), so the input is streamed once
     const int cap = k == 3 ? 64 : 128;
     pl.TN = N > 64 ? (cap >= 128 ? 4 : 2) : (N > 32 ? 2 : 1);
@@ -659,9 +693,10 @@ void plan_fs(FsPlan &pl, int B, int H, int W, int K, int N, int k) {
     pl.gx = cdiv(g.ntile, g.tiles_per_wg);
     g.gx = pl.gx; g.gy = pl.gy;
     const int PS = K * 2 + 16;
-    pl.smem = (size_t)g.R * PS + (size_t)128 * (BN * 2 + 16) + 128 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
-    if (pl.smem > 160 * 1024) return;
     pl.WN = (pl.TN >= 2 && K >= 32) ? 2 : 1;                    // eight waves wherever a wave still owns a whole 32-column tile
+    const int NW = 4 * pl.WN, CSW = 64 * (pl.TN / pl.WN) + 16;
+    pl.smem = (size_t)g.R * PS + (size_t)NW * 32 * CSW + (size_t)NW * 32 * sizeof(int) + (size_t)4 * BN * 2 * sizeof(float);
+    if (pl.smem > 160 * 1024) return;
     // (measured and dropped: 32-column blocks at two per CU for K = 64 pointwise layers -- the input is streamed twice: 24.8 ->
     // 26.5 us for 64 -> 64 at 80x80; four waves x 64 columns at two per CU: 24.8 -> 28.9 us)
     if (pl.KK * (K / 16) * (pl.TN / pl.WN) * 4 > 160) return;   // B fragments in registers: taps * k-steps * column tiles * 4 VGPRs
@@ -672,9 +707,32 @@ template <int KK, int CIN, int TN, int WN, int OCC = 1>
 int launch_fs(const FsPlan &pl, hipStream_t st) {
     auto kern = bf16_fstream_kernel<KK, CIN, TN, WN, OCC>;
     if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
+#ifdef YH_FS_STAMPS
+    static unsigned long long *dbgbuf = nullptr;
+    if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 20);
+    const bool dbg_on = getenv("YH_FS_DBG") != nullptr;
+    FsPlan pd = pl;
+    pd.g.dbg = dbg_on ? dbgbuf : nullptr;
+    hipLaunchKernelGGL(kern, dim3(pl.gx * pl.gy), dim3(256 * WN), pl.smem, st, pd.g);
+    if (dbg_on) {
+        (void)hipStreamSynchronize(st);
+        const int nb = pl.gx * pl.gy;
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        (void)hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        double a[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < nb; ++i)
+            for (int k = 0; k < 7; ++k) a[k] += (double)h[8 * i + k];
+        const double tiles = a[5] / nb;
+        fprintf(stderr, "fstream<%d,%d,%d,%d,%d> wgs %d tiles/wg %.1f | cycles per tile: stage+barrier %.0f  mfma %.0f  xch/rowpix barrier %.0f  "
+                        "Cs write+barrier %.0f  stores %.0f | wall %.1f us/wg\n", KK, CIN, TN, WN, OCC, nb, tiles, a[0] / a[5], a[1] / a[5],
+                a[2] / a[5], a[3] / a[5], a[4] / a[5], a[6] / nb / 100.0);
+    }
+    return 0;
+#else
     hipLaunchKernelGGL(kern, dim3(pl.gx * pl.gy), dim3(256 * WN), pl.smem, st, pl.g);
     YH_CHECK_LAUNCH("bf16_fstream");
     return 0;
+#endif
 }
 
 template <int KK, int CIN>
