@@ -12,6 +12,7 @@
 // The same kernel computes backward-data of a stride-1 layer (flipped taps, the backward weight pack).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -340,6 +341,102 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_kernel(const Narrow g) {
     }
 }
 
+// The same layer with bf16 storage.  Halving the bytes (315 MB: 63 us at the HBM rate) leaves the fp32 16x16x4 instruction as
+// the bound (144 of them per wave and patch: ~100 us for the layer, 272 us measured), so this form multiplies on
+// v_mfma_f32_16x16x32_bf16: the 32 dY channels of a tap are ONE instruction (16 cycles instead of 8 x 32).  LDS holds the dY
+// patch as bf16 in four planes of 8 channels, [k-octet][pixel][16 bytes], plane size a multiple of 256 bytes: the 16 rows of
+// an A fragment are 16 consecutive 16-byte slots and the four k-octets of a ds_read_b128 lane group fall into disjoint slot
+// ranges -- conflict-free.  B fragments: the backward pack [tap][K/8][ld][8] is the fragment layout (one 16-byte load per tap).
+__global__ __launch_bounds__(256) void narrow_dgrad_s2_bf16_kernel(const Narrow g) {
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    typedef NarrowIO<nbf16> IO;
+    const nbf16 *const gin = (const nbf16 *)g.in;
+    nbf16 *const gout = (nbf16 *)g.out;
+    constexpr int TW = 64, TH = 8, PW = TW / 2 + 1, PH = TH / 2 + 1, NPIX = PH * PW;
+    constexpr int PLANE = (NPIX * 16 + 255) / 256 * 256;    // bytes
+    __shared__ __attribute__((aligned(16))) unsigned char ds[4 * PLANE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % g.tiles_x;
+    bid /= g.tiles_x;
+    const int ty = bid % g.tiles_y, b = bid / g.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;                  // dX origin (even)
+    const int a0 = y0 >> 1, b0 = x0 >> 1;                  // dY origin
+    {   // g.Hi, g.Wi: dY size.  Piece = (pixel, k-octet): 16 bytes
+        constexpr int NPC = NPIX * 4, NL = (NPC + 255) / 256;
+        u32x4v rv[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k;
+            const int q = i & 3, p = i >> 2;
+            const int pr = p / PW, pc = p - pr * PW;
+            const int oy = a0 + pr, ox = b0 + pc;
+            rv[k] = u32x4v{0u, 0u, 0u, 0u};
+            if (i < NPC && oy < g.Hi && ox < g.Wi) rv[k] = *(const u32x4v *)(gin + ((size_t)(b * g.Hi + oy) * g.Wi + ox) * g.ldi + 8 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = t + 256 * k;
+            if (i < NPC) *(u32x4v *)(ds + (i & 3) * PLANE + (i >> 2) * 16) = rv[k];
+        }
+    }
+    // lane (col = ci, kk) holds w[tap][k = 8 kk .. 8 kk + 7][col]
+    bf16x8v bw[9];
+    {
+        const nbf16 *wp = (const nbf16 *)g.w;
+        const int oct = g.kpad >> 3;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            bw[tap] = __builtin_bit_cast(bf16x8v, *(const u32x4v *)(wp + ((size_t)(tap * oct + kk) * g.ldw + col) * 8));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {                       // this wave's even row (rr = 0) and odd row (rr = 1)
+        const int yl = 2 * wave + rr, y = y0 + yl, ar = yl >> 1;
+#pragma unroll
+        for (int pxp = 0; pxp < 2; ++pxp)
+#pragma unroll
+            for (int seg = 0; seg < 2; ++seg) {            // 16 pixels: x = x0 + 2 (16 seg + j) + pxp
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int jb = 16 * seg + col;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    if ((rr == 0) != (kh == 1)) continue;  // even rows: kh = 1; odd rows: kh = 0, 2
+                    const int prow = ar + (kh == 0 ? 1 : 0);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        if ((pxp == 0) != (kw == 1)) continue;
+                        const int pcol = jb + (kw == 0 ? 1 : 0);
+                        const bf16x8v a = *(const bf16x8v *)(ds + kk * PLANE + (prow * PW + pcol) * 16);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[kh * 3 + kw], acc, 0, 0, 0);
+                    }
+                }
+                if (y0 + TH <= g.Ho && x0 + TW <= g.Wo) {      // whole patch (workgroup-uniform): no per-element tests
+                    nbf16 *o = gout + ((size_t)(b * g.Ho + y) * g.Wo + x0 + 2 * (16 * seg + 4 * kk) + pxp) * g.ldo + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[r];
+                        if (g.accumulate) v += IO::load1(o + (size_t)(2 * r) * g.ldo);
+                        IO::store1(o + (size_t)(2 * r) * g.ldo, v);
+                    }
+                } else if (y < g.Ho) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int x = x0 + 2 * (16 * seg + 4 * kk + r) + pxp;
+                        if (x < g.Wo) {
+                            nbf16 *o = gout + ((size_t)(b * g.Ho + y) * g.Wo + x) * g.ldo + col;
+                            float v = acc[r];
+                            if (g.accumulate) v += IO::load1(o);
+                            IO::store1(o, v);
+                        }
+                    }
+                }
+            }
+    }
+}
+
 // Backward-weight of the narrow layers (16 -> 16 stride 1 at 160x160, stem[3] 16 -> 32 stride 2, stem[0] 3(4) -> 16 stride 2):
 //     dW[tap][ci][co] = sum over output pixels p of x[p * S + tap - 1][ci] * dY[p][co]
 // The reduction runs over PIXELS, so one v_mfma_f32_16x16x4_f32 takes 4 consecutive output pixels of a row as its k:
@@ -624,6 +721,14 @@ static int narrow_dgrad_s2_t(const T *dy, int lddy, const T *wb, int ldwb, int k
     g.Hi = (Hi - 1) / 2 + 1; g.Wi = (Wi - 1) / 2 + 1;      // dY
     g.accumulate = accumulate ? 1 : 0;
     g.tiles_x = cdiv(Wi, 64); g.tiles_y = cdiv(Hi, 8);
+    if constexpr (std::is_same<T, nbf16>::value) {
+        // the bf16-MFMA form reads dY in 16-byte pieces and the pack as fragments: K = 32 rows per tap exactly
+        if (lddy % 8 == 0 && ((uintptr_t)dy & 15) == 0 && kpad == 32 && ((uintptr_t)wb & 15) == 0) {
+            hipLaunchKernelGGL(narrow_dgrad_s2_bf16_kernel, dim3(B * g.tiles_x * g.tiles_y), dim3(256), 0, (hipStream_t)stream, g);
+            YH_CHECK_LAUNCH("conv_narrow_dgrad_s2");
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((narrow_dgrad_s2_kernel<32, 16, T>), dim3(B * g.tiles_x * g.tiles_y), dim3(256), 0, (hipStream_t)stream, g);
     YH_CHECK_LAUNCH("conv_narrow_dgrad_s2");
     return 0;
