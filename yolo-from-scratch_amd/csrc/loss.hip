@@ -124,40 +124,38 @@ struct LossArgs {
     float img;
     float lw[9], gw[9];     // per scale (box, obj, cls): weights of the total, and of its gradient
     int *counts;            // [4]
+    int *poslist[3];        // per scale: cells with an object (filled by loss_main_kernel, any order), capacity = cells[s]
     double *part;           // [nblk][3]
     float *out;             // [13]
 };
 
-__global__ void loss_count_kernel(const LossArgs a) {
-    int s = blockIdx.x >= a.blk_begin[2] ? 2 : (blockIdx.x >= a.blk_begin[1] ? 1 : 0);
-    int64_t cell = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256 + threadIdx.x;
-    const int ch = 5 + a.nc;
-    bool pos = cell < a.cells[s] && a.tgt[s][cell * ch + 4] > 0.5f;
-    unsigned long long m = __ballot(pos);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counts[s], __popcll(m));
-}
-
+// One pass over the cells.  Thread = cell: objectness term and its gradient for every cell; for a positive cell also the box
+// and class terms of the LOSS (their normalisation by the positive count happens in loss_final) and an entry in the scale's
+// positive list -- the count (atomic, per wave) is what the gradient of those terms needs, so loss_pos_kernel writes them
+// afterwards.  The gradient tensor is written as WHOLE ROWS by the workgroup that owns the cells: the span of its 256 cells
+// (zeros, the objectness gradients, the padding elements of a pixel-padded bf16 tensor) goes out in aligned 16-byte pieces --
+// no memset of the tensor before the launch, no 2-byte scattered stores into it (nc = 80: 0.28 GB fill + one partial-sector
+// write per 340-byte cell before).
 __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
     __shared__ double red[4][3];
+    __shared__ float gobj_sh[256];
     const int s = blockIdx.x >= a.blk_begin[2] ? 2 : (blockIdx.x >= a.blk_begin[1] ? 1 : 0);
-    const int64_t cell = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256 + threadIdx.x;
+    const int64_t c0 = (int64_t)(blockIdx.x - a.blk_begin[s]) * 256;
+    const int64_t cell = c0 + threadIdx.x;
     const int ch = 5 + a.nc, G = a.grid[s];
-    const float gbox = a.gw[3 * s + 0], gobj = a.gw[3 * s + 1], gcls = a.gw[3 * s + 2];
-    const int npos = a.counts[s];
+    const float gobj = a.gw[3 * s + 1];
+    const bool hasd = a.dpred[s] != nullptr;
     double lbox = 0.0, lobj = 0.0, lcls = 0.0;
+    float go = 0.f;
+    bool pos = false;
     if (cell < a.cells[s]) {
         const float *p = a.pred[s] + cell * ch;
         const float *t = a.tgt[s] + cell * ch;
-        const bool hasd = a.dpred[s] != nullptr;
-        const int64_t dbase = a.ldd[s] ? (cell / 3) * a.ldd[s] + (cell % 3) * ch : cell * ch;
-        auto dstore = [&](int e, float v) {
-            if (a.dbf16) ((__bf16 *)a.dpred[s])[dbase + e] = (__bf16)v;
-            else ((float *)a.dpred[s])[dbase + e] = v;
-        };
         const float x = p[4], z = t[4];
         lobj = (double)bce_logits(x, z);
-        if (hasd) dstore(4, (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]));
-        if (z > 0.5f) {
+        go = (yh_sigmoid(x) - z) * (gobj / (float)a.cells[s]);
+        pos = z > 0.5f;
+        if (pos) {
             int an = (int)(cell % 3);
             int64_t q = cell / 3;
             int j = (int)(q % G);
@@ -173,21 +171,28 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
             box[2] = aw * (two_w * two_w);
             box[3] = ah * (two_h * two_h);
             lbox = (double)ciou_term(box, tb, 1e-7f, gb);
-            if (hasd) {
-                float kb = gbox / (float)npos;
-                dstore(0, gb[0] * (2.0f * sg[0] * (1.f - sg[0]) / (float)G) * kb);
-                dstore(1, gb[1] * (2.0f * sg[1] * (1.f - sg[1]) / (float)G) * kb);
-                dstore(2, gb[2] * (aw * 8.0f * sg[2] * sg[2] * (1.f - sg[2])) * kb);
-                dstore(3, gb[3] * (ah * 8.0f * sg[3] * sg[3] * (1.f - sg[3])) * kb);
-            }
-            float kc = a.nc > 0 ? gcls / ((float)npos * (float)a.nc) : 0.f;
-            for (int c = 0; c < a.nc; ++c) {
-                float xc = p[5 + c], zc = t[5 + c];
-                lcls += (double)bce_logits(xc, zc);
-                if (hasd) dstore(5 + c, (yh_sigmoid(xc) - zc) * kc);
-            }
         }
     }
+    {   // positive count and list (order irrelevant: every entry is handled on its own)
+        const unsigned long long m = __ballot(pos);
+        const int lane = threadIdx.x & 63;
+        // class term of this wave's positive cells: the whole wave walks one cell's classes (coalesced reads, a fixed-order
+        // wave sum) instead of the owning thread walking nc = 80 of them while its workgroup waits
+        for (unsigned long long mm = m; mm; mm &= mm - 1) {
+            const int b = __ffsll((long long)mm) - 1;
+            const int64_t cb = c0 + (threadIdx.x & ~63) + b;
+            const float *pb = a.pred[s] + cb * ch, *tb2 = a.tgt[s] + cb * ch;
+            double v = 0.0;
+            for (int c = lane; c < a.nc; c += 64) v += (double)bce_logits(pb[5 + c], tb2[5 + c]);
+            v = wave_sum_d(v);
+            if (lane == b) lcls = v;
+        }
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&a.counts[s], __popcll(m));
+        base = __shfl(base, 0);
+        if (pos) a.poslist[s][base + __popcll(m & ((1ull << lane) - 1ull))] = (int)cell;
+    }
+    gobj_sh[threadIdx.x] = go;
     lbox = wave_sum_d(lbox); lobj = wave_sum_d(lobj); lcls = wave_sum_d(lcls);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = lbox; red[w][1] = lobj; red[w][2] = lcls; }
@@ -195,6 +200,104 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const LossArgs a) {
     if (threadIdx.x < 3)
         a.part[(size_t)blockIdx.x * 3 + threadIdx.x] =
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (!hasd) return;
+
+    // ---- this workgroup's rows of the gradient tensor: elements [e0, e1) of the (possibly pixel-padded) layout ---------------
+    const unsigned LDD = a.ldd[s] ? (unsigned)a.ldd[s] : 3u * (unsigned)ch;           // elements per pixel
+    const int64_t c1 = c0 + 256 < a.cells[s] ? c0 + 256 : a.cells[s];
+    auto elem_of = [&](int64_t c) { return (unsigned)(c / 3) * LDD + (unsigned)(c % 3) * (unsigned)ch; };
+    const unsigned e0 = elem_of(c0), e1 = c1 == a.cells[s] ? (unsigned)(a.cells[s] / 3) * LDD : elem_of(c1);
+    const unsigned pix0 = (unsigned)(c0 / 3);
+    auto value = [&](unsigned pixel, unsigned r) -> float {                         // r = element within the pixel's row
+        const unsigned an = r / (unsigned)ch, chn = r - an * (unsigned)ch;
+        if (an >= 3u || chn != 4u) return 0.f;
+        return gobj_sh[(int)((int64_t)3 * pixel + an - c0)];
+    };
+    const unsigned esz = a.dbf16 ? 2u : 4u, epp = 16u / esz;                        // element size, elements per 16-byte piece
+    unsigned char *const dp = (unsigned char *)a.dpred[s];
+    const uintptr_t b0 = (uintptr_t)dp + (uintptr_t)e0 * esz, b1 = (uintptr_t)dp + (uintptr_t)e1 * esz;
+    uintptr_t ab = (b0 + 15) & ~(uintptr_t)15, ae = b1 & ~(uintptr_t)15;
+    if (ab > b1) ab = b1;
+    if (ae < ab) ae = ab;
+    auto put1 = [&](unsigned e) {                                                     // one element (ragged ends of the span)
+        const unsigned pixel = e / LDD, r = e - pixel * LDD;
+        const float v = value(pixel, r);
+        if (a.dbf16) ((__bf16 *)dp)[e] = (__bf16)v;
+        else ((float *)dp)[e] = v;
+    };
+    const unsigned nhead = (unsigned)((ab - b0) / esz), ntail = (unsigned)((b1 - ae) / esz);
+    if (threadIdx.x < nhead) put1(e0 + threadIdx.x);
+    if (threadIdx.x < ntail) put1((unsigned)((ae - (uintptr_t)dp) / esz) + threadIdx.x);
+    const unsigned npiece = (unsigned)((ae - ab) >> 4), ea = (unsigned)((ab - (uintptr_t)dp) / esz);
+    (void)pix0;
+    for (unsigned k = threadIdx.x; k < npiece; k += 256) {
+        const unsigned e = ea + k * epp;
+        unsigned pixel = e / LDD, r = e - pixel * LDD;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = 0.f;
+            if ((unsigned)j < epp) {
+                v[j] = value(pixel, r);
+                if (++r == LDD) { r = 0; ++pixel; }
+            }
+        }
+        if (a.dbf16) {
+            typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+            const lbf16x8 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+            *(lbf16x8 *)(ab + (uintptr_t)k * 16) = o;
+        } else {
+            *(f32x4 *)(ab + (uintptr_t)k * 16) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+// Box and class gradients of the positive cells: one WAVE per list entry (lane e < 4 stores box element e, lane c the class
+// elements c, c + 64, ... -- coalesced; one thread per entry walked nc = 80 classes with a load and a store each: 190 us), the
+// same expressions in the same order as the single-pass form, with the positive count now known.  Runs after
+// loss_main_kernel wrote the rows.
+__global__ __launch_bounds__(256) void loss_pos_kernel(const LossArgs a) {
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    for (int s = 0; s < 3; ++s) {
+        if (!a.dpred[s] || a.cells[s] == 0) continue;
+        const int npos = a.counts[s];
+        const int ch = 5 + a.nc, G = a.grid[s];
+        const float gbox = a.gw[3 * s + 0], gcls = a.gw[3 * s + 2];
+        for (int i = wid; i < npos; i += nwave) {
+            const int64_t cell = a.poslist[s][i];
+            const float *p = a.pred[s] + cell * ch;
+            const float *t = a.tgt[s] + cell * ch;
+            const int64_t dbase = a.ldd[s] ? (cell / 3) * a.ldd[s] + (cell % 3) * ch : cell * ch;
+            auto dstore = [&](int e, float v) {
+                if (a.dbf16) ((__bf16 *)a.dpred[s])[dbase + e] = (__bf16)v;
+                else ((float *)a.dpred[s])[dbase + e] = v;
+            };
+            int an = (int)(cell % 3);
+            int64_t q = cell / 3;
+            int j = (int)(q % G);
+            int ii = (int)((q / G) % G);
+            float sg[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sg[e] = yh_sigmoid(p[e]);
+            float aw = a.anchors[(s * 3 + an) * 2 + 0] / a.img, ah = a.anchors[(s * 3 + an) * 2 + 1] / a.img;
+            float box[4], tb[4] = {t[0], t[1], t[2], t[3]}, gb[4];
+            box[0] = ((sg[0] * 2.0f - 0.5f) + (float)j) / (float)G;
+            box[1] = ((sg[1] * 2.0f - 0.5f) + (float)ii) / (float)G;
+            float two_w = 2.0f * sg[2], two_h = 2.0f * sg[3];
+            box[2] = aw * (two_w * two_w);
+            box[3] = ah * (two_h * two_h);
+            (void)ciou_term(box, tb, 1e-7f, gb);
+            const float kb = gbox / (float)npos;
+            float g4[4];
+            g4[0] = gb[0] * (2.0f * sg[0] * (1.f - sg[0]) / (float)G) * kb;
+            g4[1] = gb[1] * (2.0f * sg[1] * (1.f - sg[1]) / (float)G) * kb;
+            g4[2] = gb[2] * (aw * 8.0f * sg[2] * sg[2] * (1.f - sg[2])) * kb;
+            g4[3] = gb[3] * (ah * 8.0f * sg[3] * sg[3] * (1.f - sg[3])) * kb;
+            if (lane < 4) dstore(lane, lane == 0 ? g4[0] : (lane == 1 ? g4[1] : (lane == 2 ? g4[2] : g4[3])));
+            const float kc = a.nc > 0 ? gcls / ((float)npos * (float)a.nc) : 0.f;
+            for (int c = lane; c < a.nc; c += 64) dstore(5 + c, (yh_sigmoid(p[5 + c]) - t[5 + c]) * kc);
+        }
+    }
 }
 
 __global__ void loss_final_kernel(const LossArgs a) {
@@ -364,6 +467,11 @@ int fill_args(LossArgs &a, const float *const pred[3], const float *const target
     a.B = B; a.nc = nc; a.img = img;
     a.counts = (int *)ws;
     a.part = (double *)(ws + 8);
+    int *lists = (int *)(ws + 8 + 6 * (size_t)nb);
+    for (int s = 0; s < 3; ++s) {
+        a.poslist[s] = lists;
+        lists += a.cells[s];
+    }
     a.out = out;
     return 0;
 }
@@ -371,9 +479,12 @@ int fill_args(LossArgs &a, const float *const pred[3], const float *const target
 }  // namespace
 
 extern "C" int64_t yh_loss_ws(const int grid[3], int B) {
-    int64_t nb = 0;
-    for (int s = 0; s < 3; ++s) nb += cdiv64((int64_t)B * grid[s] * grid[s] * 3, 256);
-    return 8 + 6 * nb;
+    int64_t nb = 0, cells = 0;
+    for (int s = 0; s < 3; ++s) {
+        nb += cdiv64((int64_t)B * grid[s] * grid[s] * 3, 256);
+        cells += (int64_t)B * grid[s] * grid[s] * 3;
+    }
+    return 8 + 6 * nb + cells;      // positive counts | per-workgroup partial sums (double x 3) | positive lists (int32 per cell)
 }
 
 extern "C" int yh_yolo_loss(const float *const pred[3], const float *const target[3], float *const dpred[3],
@@ -397,16 +508,17 @@ extern "C" int yh_yolo_loss_ex(const float *const pred[3], const float *const ta
     YH_REQUIRE(((uintptr_t)ws & 7) == 0, "yolo_loss: workspace must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     YH_HIP(hipMemsetAsync(a.counts, 0, 4 * sizeof(int), st));
-    const int ch = 5 + nc;
-    for (int s = 0; s < 3; ++s)
-        if (a.dpred[s])      // also zeroes the padding channels of a padded bf16 gradient (they meet zero weight rows)
-            YH_HIP(hipMemsetAsync(a.dpred[s], 0, (size_t)(a.cells[s] / 3) * (a.ldd[s] ? a.ldd[s] : 3 * ch) * (a.dbf16 ? 2 : sizeof(float)), st));
     const int nb = a.blk_begin[3];
     YH_REQUIRE(nb > 0, "yolo_loss: no cells");
-    hipLaunchKernelGGL(loss_count_kernel, dim3(nb), dim3(256), 0, st, a);
-    YH_CHECK_LAUNCH("loss_count");
-    hipLaunchKernelGGL(loss_main_kernel, dim3(nb), dim3(256), 0, st, a);
+    for (int s = 0; s < 3; ++s)
+        YH_REQUIRE((int64_t)(a.cells[s] / 3 + 1) * (a.ldd[s] ? a.ldd[s] : 3 * (5 + nc)) < (1ll << 32),
+                   "yolo_loss: gradient tensor of scale %d exceeds the 32-bit element index", s);
+    hipLaunchKernelGGL(loss_main_kernel, dim3(nb), dim3(256), 0, st, a);      // writes every element of dpred (rows, padding included)
     YH_CHECK_LAUNCH("loss_main");
+    if (a.dpred[0] || a.dpred[1] || a.dpred[2]) {
+        hipLaunchKernelGGL(loss_pos_kernel, dim3(256), dim3(256), 0, st, a);
+        YH_CHECK_LAUNCH("loss_pos");
+    }
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, a);
     YH_CHECK_LAUNCH("loss_final");
     return 0;
