@@ -290,7 +290,9 @@ int yh_sppf_pool3_fwd(const float *x, int ldx, float *y1, float *y2, float *y3, 
  * (train.py:865,879), NULL grad_w = loss_w.
  * out[0..4) = total, sum box, sum obj (unweighted), sum cls (train.py:886); out[4+3s..] = per-scale
  * box/obj/cls.  dpred[s] (NULL array or NULL entry -> forward only) receives
- * sum_k grad_w[s][k] * d loss_k / d pred[s].  ws: >= yh_loss_ws(...) floats, 8-byte aligned.
+ * sum_k grad_w[s][k] * d loss_k / d pred[s]: EVERY element of it is written (whole rows, padding of a padded row
+ * included; no need to clear it first).  ws: >= yh_loss_ws(...) floats, 8-byte aligned (positive counts, per-workgroup
+ * partial sums, one int32 per cell for the lists of positive cells).
  * loss_img_size is the decode img_size (reference: always 640, quirk Q1).
  * replaces: decode_predictions + ciou_loss + yolo_loss + yolo_loss_multiscale and their autograd
  * (train.py:634-886, 909, 913). */
