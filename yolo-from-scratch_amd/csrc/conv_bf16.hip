@@ -844,7 +844,7 @@ void fill_common(BfGemm &g, const void *in, int ldi, const void *w, int ldw, int
 
 extern "C" int yh_bf16_pack_multi(const void *table, int n, void *stream) {
     YH_REQUIRE(table && n > 0, "bf16_pack_multi: bad argument");
-    hipLaunchKernelGGL(bf16_pack_multi_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const BfPackDesc *)table);
+    hipLaunchKernelGGL(bf16_pack_multi_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, (const BfPackDesc *)table);
     YH_CHECK_LAUNCH("bf16_pack_multi");
     return 0;
 }

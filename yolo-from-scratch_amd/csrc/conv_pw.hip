@@ -882,7 +882,7 @@ extern "C" int yh_conv_pw_blocks(int64_t M, int K, int Cout) {
 extern "C" int yh_pw_pack_multi(const void *table, int n, void *stream) {
     YH_REQUIRE(table && n > 0, "pw_pack_multi: bad argument");
     static_assert(sizeof(PwPackDesc) == 48, "descriptor layout is part of the ABI");
-    hipLaunchKernelGGL(pw_pack_multi_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const PwPackDesc *)table);
+    hipLaunchKernelGGL(pw_pack_multi_kernel, dim3(128, n), dim3(256), 0, (hipStream_t)stream, (const PwPackDesc *)table);
     YH_CHECK_LAUNCH("pw_pack_multi");
     return 0;
 }

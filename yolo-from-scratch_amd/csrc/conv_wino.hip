@@ -1030,7 +1030,7 @@ extern "C" int yh_wino_weights(const float *oihw, float *U, int Cout, int Cin, i
 extern "C" int yh_wino_weights_multi(const void *table, int n, void *stream) {
     YH_REQUIRE(table && n > 0, "wino_weights_multi: bad argument");
     static_assert(sizeof(WinoWDesc) == 32, "descriptor layout is part of the ABI");
-    hipLaunchKernelGGL(wino_weights_multi_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const WinoWDesc *)table);
+    hipLaunchKernelGGL(wino_weights_multi_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, (const WinoWDesc *)table);
     YH_CHECK_LAUNCH("wino_weights_multi");
     return 0;
 }

@@ -711,7 +711,7 @@ extern "C" int yh_pack_weights(const float *oihw, float *wf, float *wb, int Cout
 extern "C" int yh_pack_weights_multi(const void *table, int n_layers, void *stream) {
     YH_REQUIRE(table && n_layers > 0, "pack_weights_multi: bad argument");
     static_assert(sizeof(PackDesc) == 56, "descriptor layout is part of the ABI");
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(32, n_layers), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(256, n_layers), dim3(256), 0, (hipStream_t)stream,
                        (const PackDesc *)table);
     YH_CHECK_LAUNCH("pack_weights_multi");
     return 0;
