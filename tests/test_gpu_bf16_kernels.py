@@ -438,7 +438,7 @@ def test_loss_writes_padded_bf16_head_gradient():
     a18 = [float(v) for s in y.DEFAULT_ANCHORS for p in s for v in p]
     ws = torch.empty(int(lib.yh_loss_ws(L.int3(grids), B)) + 8, device="cuda")
     out1, out2 = torch.empty(13, device="cuda"), torch.empty(13, device="cuda")
-    d32 = [torch.empty_like(p) for p in preds]
+    d32 = [torch.full_like(p, float("nan")) for p in preds]      # the loss writes EVERY element of the gradient (whole rows)
     L.check(lib.yh_yolo_loss(L.ptr3(preds), L.ptr3(tg), L.ptr3(d32), L.floats(a18), L.int3(grids), B, nc, 640.0, None, None,
                              out1.data_ptr(), ws.data_ptr(), st))
     ldd = rup8(3 * ch)
@@ -447,6 +447,7 @@ def test_loss_writes_padded_bf16_head_gradient():
                                 640.0, None, None, out2.data_ptr(), ws.data_ptr(), st))
     assert torch.equal(out1, out2)
     for a, b in zip(d32, d16):
+        assert not bool(torch.isnan(a).any())
         assert torch.equal(b[..., :3 * ch], a.reshape(a.shape[0], a.shape[1], a.shape[2], 3 * ch).to(torch.bfloat16))
         assert bool((b[..., 3 * ch:] == 0).all())
 
