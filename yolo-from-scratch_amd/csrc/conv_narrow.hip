@@ -34,6 +34,8 @@ template <> struct NarrowIO<float> {
     static __device__ __forceinline__ f32x4 widen(raw4 v) { return v; }
     static __device__ __forceinline__ float load1(const float *p) { return *p; }
     static __device__ __forceinline__ float store1(float *p, float v) { *p = v; return v; }
+    static __device__ __forceinline__ f32x4 load4v(const float *p) { return *(const f32x4 *)p; }             // 16-byte aligned
+    static __device__ __forceinline__ f32x4 store4v(float *p, f32x4 v) { *(f32x4 *)p = v; return v; }
     // element (tap, k, n) of a weight pack [tap][K][ld]
     static __device__ __forceinline__ float weight(const float *w, int tap, int k, int n, int K, int kpad, int ld) {
         (void)kpad;
@@ -50,6 +52,12 @@ template <> struct NarrowIO<nbf16> {
     }
     static __device__ __forceinline__ float load1(const nbf16 *p) { return (float)*p; }
     static __device__ __forceinline__ float store1(nbf16 *p, float v) { const nbf16 h = (nbf16)v; *p = h; return (float)h; }
+    static __device__ __forceinline__ f32x4 load4v(const nbf16 *p) { return __builtin_convertvector(*(const nbf16x4 *)p, f32x4); }   // 8-byte aligned
+    static __device__ __forceinline__ f32x4 store4v(nbf16 *p, f32x4 v) {
+        const nbf16x4 h = __builtin_convertvector(v, nbf16x4);
+        *(nbf16x4 *)p = h;
+        return __builtin_convertvector(h, f32x4);
+    }
     // element (tap, k, n) of a bf16 pack [tap][kpad / 8][ld][8] (yh_bf16_pack_multi)
     static __device__ __forceinline__ float weight(const nbf16 *w, int tap, int k, int n, int K, int kpad, int ld) {
         (void)K;
@@ -96,9 +104,16 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) bw[tq][n] = IO::weight((const T *)g.w, wt, 4 * q + kk, 16 * n + col, CIN, g.kpad, g.ldw);
     }
-    float bias[NT];
+    // The MFMA runs TRANSPOSED (weights as the row operand, pixels as the column operand): D register r of lane (col, kk) is
+    // channel 16 n + 4 kk + r of pixel `col` -- four consecutive channels of one pixel per lane, so a tile row goes out as ONE
+    // 16-byte (bf16: 8-byte) store per lane, 16 pixels x 64 bytes contiguous per instruction (the pixel-major form stored four
+    // 4-byte elements per lane and spent a quarter of a patch's cycles on stores and their address arithmetic).
+    f32x4 bias4[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bias[n] = g.bias ? g.bias[16 * n + col] : 0.f;
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[n][r] = g.bias ? g.bias[16 * n + 4 * kk + r] : 0.f;
+    const bool vec_ok = (g.ldo & 3) == 0 && ((uintptr_t)g.out & (4 * sizeof(T) - 1)) == 0;      // workgroup-uniform
 
     // ---- staging plan (fixed for the kernel): piece k of this thread = 16 bytes (patch pixel (py, px), channel quad q);
     // gx = element offset from the patch origin, mx = LDS float offset | py << 16 | px << 24 (py = 255: past the end)
@@ -114,10 +129,19 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         mx[k] = i < NPC ? (unsigned)(((q * IH + py) * ROWSZ + sx) * 4) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
     }
     typename IO::raw4 rx[NX];
-    auto fetch = [&](int pid) {
-        const int tx = pid % g.tiles_x;
-        const int rest = pid / g.tiles_x;
-        const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
+    // patch index (tx, ty, b) of pid, advanced by the grid size without divisions
+    struct PIdx { int tx, ty, b; };
+    const int gsx = (int)gridDim.x % g.tiles_x, gsr = (int)gridDim.x / g.tiles_x, gsy = gsr % g.tiles_y, gsb = gsr / g.tiles_y;
+    auto advance = [&](PIdx &p) {
+        p.tx += gsx;
+        int c = 0;
+        if (p.tx >= g.tiles_x) { p.tx -= g.tiles_x; c = 1; }
+        p.ty += gsy + c;
+        if (p.ty >= g.tiles_y) { p.ty -= g.tiles_y; p.b += 1; }
+        p.b += gsb;
+    };
+    auto fetch = [&](const PIdx &pi) {
+        const int tx = pi.tx, ty = pi.ty, b = pi.b;
         const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
         const T *xb = gin + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
 #pragma unroll
@@ -140,18 +164,27 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
 
     // A persistent workgroup walks the patches blockIdx.x, + gridDim.x, ...; the next patch's halo is in flight (registers)
     // while the current one is multiplied and stored.
-    float csum[NT], csq[NT];                              // BatchNorm partial sums of ALL patches of this workgroup: one row
+    f32x4 csum[NT], csq[NT];                              // BatchNorm partial sums of ALL patches of this workgroup: one row
 #pragma unroll
-    for (int n = 0; n < NT; ++n) csum[n] = csq[n] = 0.f;
+    for (int n = 0; n < NT; ++n) csum[n] = csq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     int pid = blockIdx.x;
-    if (pid < npatch) fetch(pid);
+    PIdx cur, nxt;
+    {
+        const int rest = pid / g.tiles_x;
+        cur.tx = pid - rest * g.tiles_x;
+        cur.ty = rest % g.tiles_y;
+        cur.b = rest / g.tiles_y;
+    }
+    nxt = cur;
+    if (pid < npatch) fetch(cur);
     for (; pid < npatch; pid += gridDim.x) {
         __syncthreads();                                  // the previous patch's fragments are consumed
 #pragma unroll
         for (int k = 0; k < NX; ++k)
             if (t + 256 * k < NPC) *(f32x4 *)(xs + (mx[k] & 0xffffu)) = IO::widen(rx[k]);
         __syncthreads();
-        if (pid + (int)gridDim.x < npatch) fetch(pid + gridDim.x);
+        advance(nxt);
+        if (pid + (int)gridDim.x < npatch) fetch(nxt);
 
         // ---- multiply: wave w owns output rows {w, w + 4} (8-row patches) or row w, two 16-pixel halves each -----------
         f32x4 acc[MT][NT];
@@ -172,63 +205,53 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bw[tap * Q + q][n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n)      // rows = output channels (the filter fragment), columns = pixels
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[tap * Q + q][n], a[m], acc[m][n], 0, 0, 0);
             }
         }
 
-        // ---- epilogue: D register r of lane (col, kk) = pixel 4 kk + r of the segment, channel col --------------------------
-        const int tx = pid % g.tiles_x;
-        const int rest = pid / g.tiles_x;
-        const int ty = rest % g.tiles_y, b = rest / g.tiles_y;
-        const int oy0 = ty * TH, ox0 = tx * TW;
-        if (oy0 + TH <= g.Ho && ox0 + TW <= g.Wo) {       // whole patch: no per-element tests
+        // ---- epilogue: D register r of lane (col, kk) = channel 16 n + 4 kk + r of pixel `col` of the segment -------------------
+        const int b = cur.b, oy0 = cur.ty * TH, ox0 = cur.tx * TW;
+        const bool whole = oy0 + TH <= g.Ho && ox0 + TW <= g.Wo;      // whole patch: no per-pixel tests
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                T *o = gout + ((size_t)(b * g.Ho + oy0 + wave + 4 * (m >> 1)) * g.Wo + ox0 + 16 * (m & 1) + 4 * kk) * g.ldo + col;
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave + 4 * (m >> 1), ox = ox0 + 16 * (m & 1) + col;
+            if (whole || (oy < g.Ho && ox < g.Wo)) {
+                T *o = gout + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 4 * kk;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = acc[m][n] + bias4[n];
+                    if (vec_ok) {
+                        if (g.accumulate) v += IO::load4v(o + 16 * n);
+                        v = IO::store4v(o + 16 * n, v);
+                    } else {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        float v = acc[m][n][r] + bias[n];
-                        if (g.accumulate) v += IO::load1(o + (size_t)r * g.ldo + 16 * n);
-                        v = IO::store1(o + (size_t)r * g.ldo + 16 * n, v);
-                        csum[n] += v;
-                        csq[n] += v * v;
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int oy = oy0 + wave + 4 * (m >> 1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ox = ox0 + 16 * (m & 1) + 4 * kk + r;
-                        if (oy < g.Ho && ox < g.Wo) {
-                            T *o = gout + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 16 * n + col;
-                            float v = acc[m][n][r] + bias[n];
-                            if (g.accumulate) v += IO::load1(o);
-                            v = IO::store1(o, v);
-                            csum[n] += v;
-                            csq[n] += v * v;
+                        for (int r = 0; r < 4; ++r) {
+                            if (g.accumulate) v[r] += IO::load1(o + 16 * n + r);
+                            v[r] = IO::store1(o + 16 * n + r, v[r]);
                         }
                     }
+                    csum[n] += v;
+                    csq[n] += v * v;
                 }
+            }
         }
+        cur = nxt;
     }
     if (g.stats) {
         float *red = xs + Q * IH * ROWSZ * 4;                          // [4 waves][COUT][2]
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            float s = csum[n], q = csq[n];
-            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (kk == 0) {
-                red[(wave * COUT + 16 * n + col) * 2 + 0] = s;
-                red[(wave * COUT + 16 * n + col) * 2 + 1] = q;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = csum[n][r], q = csq[n][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }      // the 16 pixels of this lane group
+                if (col == 0) {
+                    red[(wave * COUT + 16 * n + 4 * kk + r) * 2 + 0] = s;
+                    red[(wave * COUT + 16 * n + 4 * kk + r) * 2 + 1] = q;
+                }
             }
-        }
         __syncthreads();
         if (t < COUT) {
             float s = 0.f, q = 0.f;
