@@ -263,6 +263,167 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
     }
 }
 
+// The first layer (3(4) -> 16, stride 2) with bf16 storage on v_mfma_f32_16x16x32_bf16.  With half the bytes the fp32 16x16x4
+// form is bound by its matrix rate (9 instructions of 32 cycles per 16-pixel tile; 165 us for 420 MB); here K = 9 taps x 4
+// channels = 36 sits in TWO instructions of 16 cycles: k slot 8 g + j of instruction i (g = lane >> 4) is tap 8 i + 2 g + (j >> 2),
+// channel j & 3 -- a lane's A fragment is the 8-byte pixels of two taps (two ds_read_b64 of the raw bf16 patch, parity planes
+// as in the fp32 form), taps 9..15 meet zero weights.  Transposed orientation (filter = row operand): a lane ends up with
+// four consecutive channels of one pixel, one 8-byte store.  Same patch walk, prefetch and statistics as narrow_conv_kernel.
+__global__ __launch_bounds__(256) void narrow_first_bf16_kernel(const Narrow g) {
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    typedef NarrowIO<nbf16> IO;
+    const nbf16 *const gin = (const nbf16 *)g.in;
+    nbf16 *const gout = (nbf16 *)g.out;
+    constexpr int S = 2, TW = 32, TH = 8, COUT = 16;
+    constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3, MT = 4;
+    constexpr int NPX = IH * IW, NX = (NPX + 255) / 256;
+    constexpr int PLANE = (IW + 1) / 2, ROWSZ = 2 * PLANE;                  // even / odd input columns as two planes per row
+    __shared__ __attribute__((aligned(16))) unsigned char xs[IH * ROWSZ * 8 + 4 * COUT * 2 * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int npatch = g.B * g.tiles_x * g.tiles_y;
+
+    // filter fragments (row operand): lane (col = output channel, kk) holds, for instruction i, taps 8 i + 2 kk and + 1
+    bf16x8v wfr[2];
+    int toff[2][2];                                                         // LDS byte offset of those taps' pixels
+    unsigned tlive[2][2];                                                   // all-ones / zero: taps 9..15 multiply zeros (not 0 x NaN)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        u32x2 h[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int tap = 8 * i + 2 * kk + e;
+            const bool live = tap < 9;
+            const int tp = live ? tap : 0;
+            h[e] = live ? *(const u32x2 *)((const nbf16 *)g.w + ((size_t)tp * (g.kpad >> 3) * g.ldw + col) * 8) : u32x2{0u, 0u};
+            const int dy = tp / 3, dx = tp - 3 * dy;
+            toff[i][e] = ((dy * 2 + (dx & 1)) * PLANE + (dx >> 1)) * 8;
+            tlive[i][e] = live ? ~0u : 0u;
+        }
+        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+        wfr[i] = __builtin_bit_cast(bf16x8v, u32x4v{h[0][0], h[0][1], h[1][0], h[1][1]});
+    }
+    f32x4 bias4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = g.bias ? g.bias[4 * kk + r] : 0.f;
+    const bool vec_ok = (g.ldo & 3) == 0 && ((uintptr_t)g.out & 7) == 0;
+
+    // staging plan: piece k of this thread = the 8 bytes of patch pixel (py, px)
+    int gx[NX];
+    unsigned mx[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int p = t + 256 * k;
+        const int py = p / IW, px = p - py * IW;
+        gx[k] = (py * g.Wi + px) * g.ldi;
+        mx[k] = p < NPX ? (unsigned)(((py * 2 + (px & 1)) * PLANE + (px >> 1)) * 8) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
+    }
+    struct PIdx { int tx, ty, b; };
+    const int gsx = (int)gridDim.x % g.tiles_x, gsr = (int)gridDim.x / g.tiles_x, gsy = gsr % g.tiles_y, gsb = gsr / g.tiles_y;
+    auto advance = [&](PIdx &p) {
+        p.tx += gsx;
+        int c = 0;
+        if (p.tx >= g.tiles_x) { p.tx -= g.tiles_x; c = 1; }
+        p.ty += gsy + c;
+        if (p.ty >= g.tiles_y) { p.ty -= g.tiles_y; p.b += 1; }
+        p.b += gsb;
+    };
+    u32x2 rx[NX];
+    auto fetch = [&](const PIdx &pi) {
+        const int iy0 = pi.ty * TH * S - 1, ix0 = pi.tx * TW * S - 1;
+        const nbf16 *xb = gin + ((ptrdiff_t)(pi.b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
+            u32x2 v = {0u, 0u};
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = *(const u32x2 *)(xb + gx[k]);
+            rx[k] = v;
+        }
+    };
+    int abase[MT];                                                          // LDS byte offset of this lane's pixel at tap (0, 0)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = wave + 4 * (m >> 1), half = m & 1;
+        abase[m] = ((row * S) * ROWSZ + 16 * half + col) * 8;
+    }
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+    int pid = blockIdx.x;
+    PIdx cur, nxt;
+    {
+        const int rest = pid / g.tiles_x;
+        cur.tx = pid - rest * g.tiles_x;
+        cur.ty = rest % g.tiles_y;
+        cur.b = rest / g.tiles_y;
+    }
+    nxt = cur;
+    if (pid < npatch) fetch(cur);
+    for (; pid < npatch; pid += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+            if (t + 256 * k < NPX) *(u32x2 *)(xs + (mx[k] & 0xffffu)) = rx[k];
+        __syncthreads();
+        advance(nxt);
+        if (pid + (int)gridDim.x < npatch) fetch(nxt);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x2 p0 = *(const u32x2 *)(xs + abase[m] + toff[i][0]), p1 = *(const u32x2 *)(xs + abase[m] + toff[i][1]);
+                typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+                const bf16x8v xf = __builtin_bit_cast(bf16x8v, u32x4v{p0[0] & tlive[i][0], p0[1] & tlive[i][0], p1[0] & tlive[i][1], p1[1] & tlive[i][1]});
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[i], xf, acc[m], 0, 0, 0);
+            }
+        }
+        const int b = cur.b, oy0 = cur.ty * TH, ox0 = cur.tx * TW;
+        const bool whole = oy0 + TH <= g.Ho && ox0 + TW <= g.Wo;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave + 4 * (m >> 1), ox = ox0 + 16 * (m & 1) + col;
+            if (whole || (oy < g.Ho && ox < g.Wo)) {
+                nbf16 *o = gout + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 4 * kk;
+                f32x4 v = acc[m] + bias4;
+                if (vec_ok) {
+                    if (g.accumulate) v += IO::load4v(o);
+                    v = IO::store4v(o, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (g.accumulate) v[r] += IO::load1(o + r);
+                        v[r] = IO::store1(o + r, v[r]);
+                    }
+                }
+                csum += v;
+                csq += v * v;
+            }
+        }
+        cur = nxt;
+    }
+    if (g.stats) {
+        float *red = (float *)(xs + IH * ROWSZ * 8);                        // [4 waves][COUT][2]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = csum[r], q = csq[r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            if (col == 0) {
+                red[(wave * COUT + 4 * kk + r) * 2 + 0] = s;
+                red[(wave * COUT + 4 * kk + r) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (t < COUT) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * COUT + t) * 2]; q += red[(w * COUT + t) * 2 + 1]; }
+            g.stats[((size_t)blockIdx.x * 2 + 0) * COUT + t] = s;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * COUT + t] = q;
+        }
+    }
+}
+
 // Backward-data of the stride-2 layer (stem[3]: dY 32 channels at 160x160 -> dX 16 channels at 320x320), same ideas.
 // dX pixel (y, x) of parity (py, px) = (y & 1, x & 1), a = y >> 1, b = x >> 1, receives
 //   py = 0: kh = 1 from dY row a            py = 1: kh = 0 from row a + 1, kh = 2 from row a
@@ -784,7 +945,16 @@ static int narrow_conv_t(const T *x, int ldx, const T *w, int ldw, int kpad, con
     hipStream_t st = (hipStream_t)stream;
     const int grid = narrow_conv_grid(B * nt);
     if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1, T>), dim3(grid), dim3(256), 0, st, g);
-    else if (Cin == 4) hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2, T>), dim3(grid), dim3(256), 0, st, g);
+    else if (Cin == 4) {
+        bool fast = false;
+        if constexpr (std::is_same<T, nbf16>::value)      // the bf16-MFMA form reads pixels and filter octets in 8-byte pieces
+            fast = ldx % 4 == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)w & 7) == 0 && !flip_taps;
+#ifdef YH_WGS_TUNE
+        if (getenv("YH_NO_FIRST_BF16")) fast = false;
+#endif
+        if (fast) hipLaunchKernelGGL(narrow_first_bf16_kernel, dim3(grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2, T>), dim3(grid), dim3(256), 0, st, g);
+    }
     else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2, T>), dim3(grid), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow");
     return 0;
