@@ -424,6 +424,171 @@ __global__ __launch_bounds__(256) void narrow_first_bf16_kernel(const Narrow g) 
     }
 }
 
+// stem[3] (16 -> 32, stride 2) forward with bf16 storage on v_mfma_f32_16x16x32_bf16, same construction as the first layer:
+// K = 9 taps x 16 channels = 144 in FIVE instructions per 16-pixel x 16-channel tile (k slot 8 g + j of instruction i = tap
+// 2 i + (g >> 1), channel 8 (g & 1) + j; the tenth tap slot is masked), against 36 of the fp32 form.  LDS holds the raw bf16
+// patch, 32 bytes per pixel in parity planes; a lane's fragment is one ds_read_b128.
+__global__ __launch_bounds__(256) void narrow_s2_16x32_bf16_kernel(const Narrow g) {
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    typedef NarrowIO<nbf16> IO;
+    const nbf16 *const gin = (const nbf16 *)g.in;
+    nbf16 *const gout = (nbf16 *)g.out;
+    constexpr int S = 2, TW = 32, TH = 4, COUT = 32, NT = 2, MT = 2;
+    constexpr int IW = (TW - 1) * S + 3, IH = (TH - 1) * S + 3;
+    constexpr int NPC = IH * IW * 2, NX = (NPC + 255) / 256;                // 16-byte pieces: (pixel, channel octet)
+    constexpr int PLANE = (IW + 1) / 2, ROWSZ = 2 * PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char xs[IH * ROWSZ * 32 + 4 * COUT * 2 * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int npatch = g.B * g.tiles_x * g.tiles_y;
+
+    bf16x8v wfr[5][NT];
+    int toff[5];
+    unsigned tlive[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int tap = 2 * i + (kk >> 1);
+        const bool live = tap < 9;
+        const int tp = live ? tap : 0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            wfr[i][n] = __builtin_bit_cast(bf16x8v, live ? *(const u32x4v *)((const nbf16 *)g.w + ((size_t)(tp * (g.kpad >> 3) + (kk & 1)) * g.ldw + 16 * n + col) * 8)
+                                                         : u32x4v{0u, 0u, 0u, 0u});
+        const int dy = tp / 3, dx = tp - 3 * dy;
+        toff[i] = ((dy * 2 + (dx & 1)) * PLANE + (dx >> 1)) * 32 + (kk & 1) * 16;
+        tlive[i] = live ? ~0u : 0u;
+    }
+    f32x4 bias4[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[n][r] = g.bias ? g.bias[16 * n + 4 * kk + r] : 0.f;
+    const bool vec_ok = (g.ldo & 3) == 0 && ((uintptr_t)g.out & 7) == 0;
+
+    int gx[NX];
+    unsigned mx[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = t + 256 * k;
+        const int oc = i & 1, p = i >> 1;
+        const int py = p / IW, px = p - py * IW;
+        gx[k] = (py * g.Wi + px) * g.ldi + 8 * oc;
+        mx[k] = i < NPC ? (unsigned)(((py * 2 + (px & 1)) * PLANE + (px >> 1)) * 32 + oc * 16) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
+    }
+    struct PIdx { int tx, ty, b; };
+    const int gsx = (int)gridDim.x % g.tiles_x, gsr = (int)gridDim.x / g.tiles_x, gsy = gsr % g.tiles_y, gsb = gsr / g.tiles_y;
+    auto advance = [&](PIdx &p) {
+        p.tx += gsx;
+        int c = 0;
+        if (p.tx >= g.tiles_x) { p.tx -= g.tiles_x; c = 1; }
+        p.ty += gsy + c;
+        if (p.ty >= g.tiles_y) { p.ty -= g.tiles_y; p.b += 1; }
+        p.b += gsb;
+    };
+    u32x4v rx[NX];
+    auto fetch = [&](const PIdx &pi) {
+        const int iy0 = pi.ty * TH * S - 1, ix0 = pi.tx * TW * S - 1;
+        const nbf16 *xb = gin + ((ptrdiff_t)(pi.b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
+            u32x4v v = {0u, 0u, 0u, 0u};
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = *(const u32x4v *)(xb + gx[k]);
+            rx[k] = v;
+        }
+    };
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = ((wave * S) * ROWSZ + 16 * m + col) * 32;       // row = wave, half = m
+    f32x4 csum[NT], csq[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) csum[n] = csq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int pid = blockIdx.x;
+    PIdx cur, nxt;
+    {
+        const int rest = pid / g.tiles_x;
+        cur.tx = pid - rest * g.tiles_x;
+        cur.ty = rest % g.tiles_y;
+        cur.b = rest / g.tiles_y;
+    }
+    nxt = cur;
+    if (pid < npatch) fetch(cur);
+    for (; pid < npatch; pid += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NX; ++k)
+            if (t + 256 * k < NPC) *(u32x4v *)(xs + (mx[k] & 0xffffu)) = rx[k];
+        __syncthreads();
+        advance(nxt);
+        if (pid + (int)gridDim.x < npatch) fetch(nxt);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                u32x4v p = *(const u32x4v *)(xs + abase[m] + toff[i]);
+                p[0] &= tlive[i]; p[1] &= tlive[i]; p[2] &= tlive[i]; p[3] &= tlive[i];
+                const bf16x8v xf = __builtin_bit_cast(bf16x8v, p);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[i][n], xf, acc[m][n], 0, 0, 0);
+            }
+        const int b = cur.b, oy0 = cur.ty * TH, ox0 = cur.tx * TW;
+        const bool whole = oy0 + TH <= g.Ho && ox0 + TW <= g.Wo;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = oy0 + wave, ox = ox0 + 16 * m + col;
+            if (whole || (oy < g.Ho && ox < g.Wo)) {
+                nbf16 *o = gout + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * g.ldo + 4 * kk;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = acc[m][n] + bias4[n];
+                    if (vec_ok) {
+                        if (g.accumulate) v += IO::load4v(o + 16 * n);
+                        v = IO::store4v(o + 16 * n, v);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (g.accumulate) v[r] += IO::load1(o + 16 * n + r);
+                            v[r] = IO::store1(o + 16 * n + r, v[r]);
+                        }
+                    }
+                    csum[n] += v;
+                    csq[n] += v * v;
+                }
+            }
+        }
+        cur = nxt;
+    }
+    if (g.stats) {
+        float *red = (float *)(xs + IH * ROWSZ * 32);                       // [4 waves][COUT][2]
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = csum[n][r], q = csq[n][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+                if (col == 0) {
+                    red[(wave * COUT + 16 * n + 4 * kk + r) * 2 + 0] = s;
+                    red[(wave * COUT + 16 * n + 4 * kk + r) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (t < COUT) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * COUT + t) * 2]; q += red[(w * COUT + t) * 2 + 1]; }
+            g.stats[((size_t)blockIdx.x * 2 + 0) * COUT + t] = s;
+            g.stats[((size_t)blockIdx.x * 2 + 1) * COUT + t] = q;
+        }
+    }
+}
+
 // Backward-data of the stride-2 layer (stem[3]: dY 32 channels at 160x160 -> dX 16 channels at 320x320), same ideas.
 // dX pixel (y, x) of parity (py, px) = (y & 1, x & 1), a = y >> 1, b = x >> 1, receives
 //   py = 0: kh = 1 from dY row a            py = 1: kh = 0 from row a + 1, kh = 2 from row a
@@ -955,7 +1120,13 @@ static int narrow_conv_t(const T *x, int ldx, const T *w, int ldw, int kpad, con
         if (fast) hipLaunchKernelGGL(narrow_first_bf16_kernel, dim3(grid), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((narrow_conv_kernel<4, 16, 2, T>), dim3(grid), dim3(256), 0, st, g);
     }
-    else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2, T>), dim3(grid), dim3(256), 0, st, g);
+    else {
+        bool fast = false;
+        if constexpr (std::is_same<T, nbf16>::value)      // the bf16-MFMA form: 16-byte pieces of pixels and of the filter pack
+            fast = ldx % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && kpad == 16 && !flip_taps;
+        if (fast) hipLaunchKernelGGL(narrow_s2_16x32_bf16_kernel, dim3(grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2, T>), dim3(grid), dim3(256), 0, st, g);
+    }
     YH_CHECK_LAUNCH("conv_narrow");
     return 0;
 }

@@ -602,7 +602,9 @@ class Plan:
             # (8-byte pieces: twice the load instructions per byte of the fp32 form -- these kernels are bound by instruction
             # issue and latency, not by bytes).  Each pass takes the faster kernel; YH_BF16_NARROW=all forces the narrow ones.
             every = False
-            r.narrow_f = bool(use_nar and (r.cin_k == 4 or (every and r.cin == cin_real)) and lib.yh_conv_narrow_ok(r.cin_k, r.cout, 3, r.s))
+            # round 3: stem[3] forward (16 -> 32, stride 2) has a bf16-MFMA form of the narrow kernel (0.112 -> 0.075 ms)
+            stem3 = r.s == 2 and r.cin == 16 and r.cout == 32 and r.cin == cin_real and r.x.ld % 8 == 0
+            r.narrow_f = bool(use_nar and (r.cin_k == 4 or stem3 or (every and r.cin == cin_real)) and lib.yh_conv_narrow_ok(r.cin_k, r.cout, 3, r.s))
             r.narrow_w = bool(use_nar and (r.cin_k == 4 or r.s == 1 or every) and
                               lib.yh_conv_narrow_bwd_weight_ok(r.cin_k, min(cin_real, r.cin_k), r.cout, 3, r.s))
             r.narrow_b = bool(use_nar and r.need_dx and r.pair is None and r.cin == cin_real and
