@@ -226,7 +226,8 @@ def roofline_bf16(model, trainer, imgs, targets, nc, img, batch, size):
     roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_note": note,
             "kernel": "forward convolutions: bf16_fstream_kernel (stride-1 layers as a flat pixel stream: halo ring in LDS, B fragments in "
-                      "registers) + bf16_gemm_kernel (stride-2 and wide-K layers: gather implicit GEMM), both on v_mfma_f32_32x32x16_bf16",
+                      "registers) + bf16_gemm_kernel (stride-2 and wide-K layers: gather implicit GEMM), both on v_mfma_f32_32x32x16_bf16; the "
+                      "first layer and stem[3] on direct v_mfma_f32_16x16x32_bf16 kernels (narrow_first_bf16_kernel, narrow_s2_16x32_bf16_kernel)",
             "kernel_ms_per_step": round(conv_ms, 3), "launches_per_step": n_launch,
             "algorithmic_gbytes_per_step": round(nbytes / 1e9, 3),
             "algorithmic_gflop_per_step": round(flops / 1e9, 2),
