@@ -346,6 +346,29 @@ __global__ __launch_bounds__(256) void bf16_gemm_kernel(const BfGemmSet gs) {
                     csq[j] += vq * vq;
                 }
             }
+    } else if (g.out_f32 && !g.accumulate && g.dense && m0 + BM <= g.M) {
+        // fp32 outputs of whole row blocks (the detection heads: N = 3 (5 + nc) = 255 is odd, so rows are 4-byte aligned only):
+        // straight-line stores with ONE column predicate per lane and tile -- the general loop below tests every element and
+        // was 187 us for the 80 x 80 head at nc = 80 (418 MB: 84 us at the HBM rate)
+        bool nok[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) nok[j] = n0 + wn * TN * 32 + j * 32 + lr < g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * TM * 32 + i * 32 + mfma_row(q, lh);
+                float *orow = (float *)g.out + (size_t)m * g.ldo + n0 + wn * TN * 32 + lr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float v = acc[i][j][q] + bias_v[j];
+                    if (nok[j]) {
+                        orow[j * 32] = v;
+                        csum[j] += v;
+                        csq[j] += v * v;
+                    }
+                }
+            }
     } else {
         // (always_inline: a closure that is called would take the address of the kernel-argument struct, which then lives in scratch)
         auto direct = [&](auto f32_c, auto acc_c) __attribute__((always_inline)) {

@@ -300,12 +300,12 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(const LossArgs a) {
     }
 }
 
-__global__ void loss_final_kernel(const LossArgs a) {
-    __shared__ double sh[3][3][4];
+__global__ __launch_bounds__(1024) void loss_final_kernel(const LossArgs a) {
+    __shared__ double sh[3][3][16];
     const int t = threadIdx.x, w = t >> 6;
     for (int s = 0; s < 3; ++s) {
         double v[3] = {0.0, 0.0, 0.0};
-        for (int b = a.blk_begin[s] + t; b < a.blk_begin[s + 1]; b += 256)
+        for (int b = a.blk_begin[s] + t; b < a.blk_begin[s + 1]; b += 1024)
             for (int k = 0; k < 3; ++k) v[k] += a.part[(size_t)b * 3 + k];
         for (int k = 0; k < 3; ++k) {
             double r = wave_sum_d(v[k]);
@@ -317,9 +317,8 @@ __global__ void loss_final_kernel(const LossArgs a) {
         float total = 0.f, tb = 0.f, to = 0.f, tc = 0.f;
         for (int s = 0; s < 3; ++s) {
             if (a.cells[s] == 0) { a.out[4 + 3 * s] = a.out[5 + 3 * s] = a.out[6 + 3 * s] = 0.f; continue; }
-            double sb = sh[s][0][0] + sh[s][0][1] + sh[s][0][2] + sh[s][0][3];
-            double so = sh[s][1][0] + sh[s][1][1] + sh[s][1][2] + sh[s][1][3];
-            double sc = sh[s][2][0] + sh[s][2][1] + sh[s][2][2] + sh[s][2][3];
+            double sb = 0.0, so = 0.0, sc = 0.0;
+            for (int w2 = 0; w2 < 16; ++w2) { sb += sh[s][0][w2]; so += sh[s][1][w2]; sc += sh[s][2][w2]; }
             int n = a.counts[s];
             float box = n > 0 ? (float)(sb / (double)n) : 0.f;
             float obj = (float)(so / (double)a.cells[s]);
@@ -519,7 +518,7 @@ extern "C" int yh_yolo_loss_ex(const float *const pred[3], const float *const ta
         hipLaunchKernelGGL(loss_pos_kernel, dim3(256), dim3(256), 0, st, a);
         YH_CHECK_LAUNCH("loss_pos");
     }
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, st, a);
     YH_CHECK_LAUNCH("loss_final");
     return 0;
 }
