@@ -190,6 +190,17 @@ int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const flo
                      float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
 int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                           int W, int Cin, int Cout, int accumulate, void *stream);
+/* The same two passes with the input patch of a 2-D block of tiles staged once through LDS (round 4): K % 16 == 0, bit-identical
+ * results.  icoef (or NULL): the input prologue table [scale | shift | gate], three rows of Cin floats icoef_ld floats apart -- the
+ * PRODUCER's BatchNorm + SiLU fused into the staging: the kernel reads the producer's raw convolution output x and uses
+ * z = x * scale[k] + shift[k], silu(z) where gate[k] != 0, as its input; zero padding is applied after the activation, so the
+ * normalised tensor never exists in memory (replaces the ConvBlock.forward hand-over, train.py:253-265).
+ * bn_partials: [yh_conv_wino_lds_blocks][2][Cout]. */
+int yh_conv_wino_lds_blocks(int B, int H, int W);
+int yh_conv_wino_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *U, int ldu, const float *bias,
+                         float *y, int ldy, float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
+int yh_conv_wino_bwd_data_lds(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H, int W, int Cin,
+                              int Cout, int accumulate, void *stream);
 /* Backward-weight in the Winograd domain (Cin % 32 == 0, Cout % 32 == 0, even H, W): dw (OIHW) = the same sum as
  * yh_conv_bwd_weight for k = 3, s = 1, deterministic (fixed-order reduction of per-workgroup [9][Cin][Cout] slabs
  * through ws, ws_floats >= yh_conv_wino_bwd_weight_ws(...)). */

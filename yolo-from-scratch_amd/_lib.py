@@ -64,6 +64,9 @@ _SIGS = {
     "yh_wino_weights_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_wino_blocks": (i32, [i32, i32, i32]),
     "yh_conv_wino_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_wino_lds_blocks": (i32, [i32, i32, i32]),
+    "yh_conv_wino_fwd_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_wino_bwd_data_lds": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32]),
     "yh_conv_fwd_fused_splitk": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32,

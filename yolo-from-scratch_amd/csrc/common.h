@@ -64,6 +64,15 @@ __device__ __forceinline__ float yh_sigmoid(float x) { return 1.0f / (1.0f + exp
 // Saturates correctly (exp -> inf gives 0, exp -> 0 gives 1); the loss and the detection threshold keep yh_sigmoid.
 __device__ __forceinline__ float yh_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Input prologue of the convolution kernels (round 4): the PRODUCER's BatchNorm + SiLU applied by the consumer while it stages its
+// operand, so the normalised activation never exists in memory.  Per input channel a table row [scale | shift | gate]:
+// z = x * scale + shift, then silu(z) where gate != 0 (materialised channels of a concatenation carry scale 1, shift 0, gate 0).
+// Same expression, same hardware exp / rcp as bn_silu_fwd_kernel: a fused consumer sees the values the separate pass would have stored.
+__device__ __forceinline__ float yh_prologue(float x, float scale, float shift, float gate) {
+    const float z = x * scale + shift;
+    return gate != 0.f ? z * yh_sigmoid_fast(z) : z;
+}
+
 // 64-lane butterfly sum; every lane ends with the total.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

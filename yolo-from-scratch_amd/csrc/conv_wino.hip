@@ -42,6 +42,11 @@ struct Wino {
     int ldr, act, up2;          // act: SiLU on (acc + bias); up2: each output pixel replicated 2x2 (out is (B,2H,2W))
     unsigned tw_magic, tpi_magic;
     int tw_shift, tpi_shift;
+    // LDS-staged kernel (wino_lds_kernel): fused producer activation, block geometry and patch layout (set by the launcher)
+    const float *icoef;             // input prologue table [scale | shift | gate] (icoef_ld floats apart): input = z = x * scale[k] + shift[k],
+    int icoef_ld;                   // then silu(z) where gate[k] != 0; applied while the patch is staged; null = plain input
+    int TH, R, C, ncb;              // tile rows per image; tile rows x tile columns per workgroup (R C <= 32); column blocks per tile row
+    int PCh, plane, bufsz, toff_ofs;// half-row stride and plane stride of the patch (float4 units); one patch buffer, tile-offset table (floats)
 #ifdef YH_WINO_STAMPS
     unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps
 #endif
@@ -55,10 +60,223 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
 }
 
+// Output transform + store + BatchNorm partial sums, shared by the register-direct and the LDS-staged kernels.  `toff[32]` (LDS):
+// pixel index of each tile's top-left output ((b H + 2 ty) W + 2 tx), -1 for an empty tile slot; `whole_tiles`: all 32 slots hold tiles
+// (wave-uniform); `tgrp`: the workgroup's row of the BatchNorm partial-sum table.  Every wave has passed a barrier after its last use
+// of `smem` before the call.
+template <int NT>
+__device__ __forceinline__ void wino_epilogue(const Wino &g, f32x16 (&acc)[4][NT], float *smem, const int *toff, bool whole_tiles,
+                                              int tgrp, int n0) {
+    constexpr int BNW = 32 * NT;
+    constexpr int IMG_FLOATS = 6 * 4 * NT * 256;                   // training epilogue: six register images of 16 NT floats per lane
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    // ---- output transform, training form (no activation / residual / upsample / BatchNorm table) ----------------------------
+    // Y = A^T M A per tile.  The nu-contraction is lane-local: T[c] = (m0 + m1) + m2 | (m1 - m2) - m3 (output column c).  The
+    // xi-contraction needs three of the four waves' T: wave w produces output row w >> 1, column w & 1 of every tile, so the
+    // waves swap whole REGISTER IMAGES through LDS (six images, 16-byte writes and reads, lane-contiguous: conflict-free) and
+    // each stores its quarter of the outputs straight from the MFMA layout (32 consecutive channels = 128 bytes per row).
+    // Same values bit for bit as the general epilogue below ((T0 + T1) + T2, (T1 - T2) - T3); in-kernel stamps: that one
+    // took 11 000 cycles per workgroup at one wave per SIMD (64 4-byte LDS writes + 64 reads per lane, per-tile divisions).
+    if (!(g.act | g.up2 | (g.res != nullptr))) {
+        float T[2][NT][16];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+                T[0][j][r] = m0 + m1 + m2;
+                T[1][j][r] = m1 - m2 - m3;
+            }
+        auto put = [&](int id, const float (&v)[NT][16]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4 *)(smem + ((size_t)((id * NT + j) * 4 + q) * 64 + lane) * 4) = f32x4{v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]};
+        };
+        auto get = [&](int id, float (&v)[NT][16]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 x = *(const f32x4 *)(smem + ((size_t)((id * NT + j) * 4 + q) * 64 + lane) * 4);
+                    v[j][4 * q] = x[0]; v[j][4 * q + 1] = x[1]; v[j][4 * q + 2] = x[2]; v[j][4 * q + 3] = x[3];
+                }
+        };
+        // images: 0 = T0[1], 1 = T1[0], 2 = T1[1], 3 = T2[0], 4 = T2[1], 5 = T3[0]
+        if (wave == 0) put(0, T[1]);
+        else if (wave == 1) { put(1, T[0]); put(2, T[1]); }
+        else if (wave == 2) { put(3, T[0]); put(4, T[1]); }
+        else put(5, T[0]);
+        __syncthreads();
+        float Y[NT][16], L1[NT][16], L2[NT][16];
+        if (wave == 0) {            // row 0, column 0: (T0[0] + T1[0]) + T2[0]
+            get(1, L1); get(3, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (T[0][j][r] + L1[j][r]) + L2[j][r];
+        } else if (wave == 1) {     // row 0, column 1: (T0[1] + T1[1]) + T2[1]
+            get(0, L1); get(4, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] + T[1][j][r]) + L2[j][r];
+        } else if (wave == 2) {     // row 1, column 0: (T1[0] - T2[0]) - T3[0]
+            get(1, L1); get(5, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - T[0][j][r]) - L2[j][r];
+        } else {                    // row 1, column 1: (T1[1] - T2[1]) - T3[1]
+            get(2, L1); get(4, L2);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - L2[j][r]) - T[1][j][r];
+        }
+        // register r of this lane = tile (r & 3) + 8 (r >> 2) + 4 lh of the group: four consecutive offsets per 16-byte read
+        int tp[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const i32x4 x = *(const i32x4 *)(toff + 8 * q + 4 * lh);
+            tp[4 * q] = x[0]; tp[4 * q + 1] = x[1]; tp[4 * q + 2] = x[2]; tp[4 * q + 3] = x[3];
+        }
+        const int pc = (wave >> 1) * g.W + (wave & 1);
+        gfloat *const outg = yh_global(g.out);
+        const bool whole = whole_tiles && n0 + BNW <= g.N;                   // wave-uniform
+        float cs[NT], cq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + 32 * j + lr;
+            const bool nok = n < g.N;
+            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+            cs[j] = cq[j] = 0.f;
+            if (whole) {
+                if (!g.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = Y[j][r] + bias;
+                        outg[(unsigned)((tp[r] + pc) * g.ldo + n)] = v;
+                        cs[j] += v;
+                        cq[j] += v * v;
+                    }
+                } else {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = outg[(unsigned)((tp[r] + pc) * g.ldo + n)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = Y[j][r] + bias + old[r];
+                        outg[(unsigned)((tp[r] + pc) * g.ldo + n)] = v;
+                        cs[j] += v;
+                        cq[j] += v * v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (nok && tp[r] >= 0) {
+                        gfloat *o = outg + (unsigned)((tp[r] + pc) * g.ldo + n);
+                        float v = Y[j][r] + bias;
+                        if (g.accumulate) v += *o;
+                        *o = v;
+                        cs[j] += v;
+                        cq[j] += v * v;
+                    }
+            }
+        }
+        if (g.stats) {
+            float *red = smem + IMG_FLOATS + 32;                          // [4 waves][BNW][2]
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float s = cs[j] + __shfl_xor(cs[j], 32), q = cq[j] + __shfl_xor(cq[j], 32);
+                if (lh == 0) { red[(wave * BNW + 32 * j + lr) * 2] = s; red[(wave * BNW + 32 * j + lr) * 2 + 1] = q; }
+            }
+            __syncthreads();
+            if (t < BNW && n0 + t < g.N) {
+                const float a0 = (red[t * 2] + red[(BNW + t) * 2]) + (red[(2 * BNW + t) * 2] + red[(3 * BNW + t) * 2]);
+                const float a1 = (red[t * 2 + 1] + red[(BNW + t) * 2 + 1]) + (red[(2 * BNW + t) * 2 + 1] + red[(3 * BNW + t) * 2 + 1]);
+                g.stats[((size_t)tgrp * 2 + 0) * g.N + n0 + t] = a0;
+                g.stats[((size_t)tgrp * 2 + 1) * g.N + n0 + t] = a1;
+            }
+        }
+        return;
+    }
+
+    // ---- output transform, general form.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
+    float *S = smem;                           // [xi 4][j 2][tile 32][ch BNW]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
+            S[((wave * 2 + 0) * TPB + row) * BNW + j * 32 + lr] = m0 + m1 + m2;
+            S[((wave * 2 + 1) * TPB + row) * BNW + j * 32 + lr] = m1 - m2 - m3;
+        }
+    __syncthreads();
+    // xi-contraction + store: thread = (channel, tile group); 256 / BNW tile groups
+    constexpr int TG = 256 / BNW;
+    const int ch = t % BNW, tgp = t / BNW, n = n0 + ch;
+    const bool nok = n < g.N;
+    const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+    float csum = 0.f, csq = 0.f;
+    for (int it = 0; it < TPB / TG; ++it) {
+        const int tl = tgp + TG * it, tp0 = toff[tl];      // pixel index of the tile's top-left output; -1 = no such tile
+        if (tp0 < 0 || !nok) continue;
+        float s[4][2];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[xi][j] = S[((xi * 2 + j) * TPB + tl) * BNW + ch];
+        float *o = g.out + (size_t)tp0 * g.ldo + n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float y0 = s[0][j] + s[1][j] + s[2][j] + bias;
+            float y1 = s[1][j] - s[2][j] - s[3][j] + bias;
+            float *o0 = o + (size_t)j * g.ldo, *o1 = o0 + (size_t)g.W * g.ldo;
+            if (g.accumulate) { y0 += *o0; y1 += *o1; }
+            if (g.act | g.up2 | (g.res != nullptr)) {          // inference form (uniform branch)
+                if (g.act) { y0 = y0 * yh_sigmoid(y0); y1 = y1 * yh_sigmoid(y1); }
+                const size_t p0 = (size_t)tp0 + j;
+                if (g.res) { y0 += g.res[p0 * g.ldr + n]; y1 += g.res[(p0 + g.W) * g.ldr + n]; }
+                if (g.up2) {
+                    // output (b, 2 ty, 2 tx + j) of the (B, H, W) lattice = row tp0 / W, column tp0 % W + j; replicated 2 x 2 into (B, 2H, 2W)
+                    const unsigned rowg = (unsigned)tp0 / (unsigned)g.W, colg = (unsigned)tp0 - rowg * (unsigned)g.W + j;
+                    const size_t rs = (size_t)(2 * g.W) * g.ldo;
+                    float *u0 = g.out + ((size_t)(2 * rowg) * 2 * g.W + 2 * colg) * g.ldo + n;
+                    float *u1 = u0 + 2 * rs;
+                    u0[0] = y0; u0[g.ldo] = y0; u0[rs] = y0; u0[rs + g.ldo] = y0;
+                    u1[0] = y1; u1[g.ldo] = y1; u1[rs] = y1; u1[rs + g.ldo] = y1;
+                    continue;
+                }
+            }
+            *o0 = y0; *o1 = y1;
+            csum += y0 + y1;
+            csq += y0 * y0 + y1 * y1;
+        }
+    }
+    if (g.stats) {
+        float *red = smem + 4 * 2 * TPB * BNW;   // [TG][BNW][2]
+        red[(tgp * BNW + ch) * 2 + 0] = csum;
+        red[(tgp * BNW + ch) * 2 + 1] = csq;
+        __syncthreads();
+        if (tgp == 0 && nok) {                   // ch == t: the thread that looked its column up
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < TG; ++w) { a0 += red[(w * BNW + t) * 2]; a1 += red[(w * BNW + t) * 2 + 1]; }
+            g.stats[((size_t)tgrp * 2 + 0) * g.N + n] = a0;
+            g.stats[((size_t)tgrp * 2 + 1) * g.N + n] = a1;
+        }
+    }
+}
+
 template <int NT, int PIPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ? 2 : 1, PIPE == 1 ? (NT == 1 ? 3 : 2) : (PIPE == 3 && NT == 1 ? 2 : 1)))) void wino_kernel(const Wino g) {
     constexpr int BNW = 32 * NT;
-    constexpr int IMG_FLOATS = 6 * 4 * NT * 256;                   // training epilogue: six register images of 16 NT floats per lane
+    constexpr int TOFF = 4 * 2 * TPB * BNW + 256 * 2;              // tile offsets: behind everything either epilogue form uses
     extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats) / images + tile offsets + stats
 
 #ifdef YH_WINO_STAMPS
@@ -89,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
         int b = fdiv(tg, g.tpi_magic, g.tpi_shift), r = tg - b * g.TPI;
         int ty = fdiv(r, g.tw_magic, g.tw_shift), tx = r - ty * g.TW;
         // pixel index of the tile's top-left output, for the training epilogue (read after its barrier; -1 = no such tile)
-        if (wave == 0 && lh == 0) ((int *)(smem + IMG_FLOATS))[lr] = tv ? (b * g.H + 2 * ty) * g.W + 2 * tx : -1;
+        if (wave == 0 && lh == 0) ((int *)(smem + TOFF))[lr] = tv ? (b * g.H + 2 * ty) * g.W + 2 * tx : -1;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             int iy = 2 * ty - 1 + (rr ? rb : ra);
@@ -204,214 +422,237 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ?
 #ifdef YH_WINO_STAMPS
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- output transform, training form (no activation / residual / upsample / BatchNorm table) ----------------------------
-    // Y = A^T M A per tile.  The nu-contraction is lane-local: T[c] = (m0 + m1) + m2 | (m1 - m2) - m3 (output column c).  The
-    // xi-contraction needs three of the four waves' T: wave w produces output row w >> 1, column w & 1 of every tile, so the
-    // waves swap whole REGISTER IMAGES through LDS (six images, 16-byte writes and reads, lane-contiguous: conflict-free) and
-    // each stores its quarter of the outputs straight from the MFMA layout (32 consecutive channels = 128 bytes per row).
-    // Same values bit for bit as the general epilogue below ((T0 + T1) + T2, (T1 - T2) - T3); in-kernel stamps: that one
-    // took 11 000 cycles per workgroup at one wave per SIMD (64 4-byte LDS writes + 64 reads per lane, per-tile divisions).
-    if (!(g.act | g.up2 | (g.res != nullptr))) {
-        float T[2][NT][16];
+    wino_epilogue<NT>(g, acc, smem, (const int *)(smem + TOFF), tile0 + TPB <= g.ntiles, tgrp, n0);
+#ifdef YH_WINO_STAMPS
+    if (g.dbg && t == 0) {
+        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
+        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same convolution with the INPUT PATCH STAGED THROUGH LDS (round 4).  What bounded wino_kernel above was not bytes but cache
+// lines: a lane's 16-byte pixel loads touch 64 different lines per instruction and the four transform-row waves request every
+// pixel 3.4 times, so the loop ran at the CU's line rate (1.45x its MFMA time).  Here a workgroup owns a 2-D block of R x C tiles
+// (R C <= 32; rows are LINEAR tile rows over batch x image rows, so blocks may span images) and, per chunk of 8 input channels,
+// reads the block's (2R+2) x (2C+2) input patch ONCE (16 bytes per thread and piece, two or three pieces per thread), applies the
+// producer's BatchNorm scale / shift + SiLU on the way if asked to (the normalised activation then never exists in HBM; padding
+// pixels are zeros AFTER the activation, as in the reference), and parks it in LDS as P[k-quad][column parity][row][column / 2]
+// float4s.  A wave's operand read is a conflict-free ds_read_b128 for the block shapes the launcher picks (the half-row stride
+// PCh is searched on the host); two patch buffers, one barrier per chunk.  Weights: as before (private coalesced float4 loads of
+// U), but each transform row's fragments are re-loaded IN PLACE for the next chunk right behind the eight MFMAs that consumed
+// them -- prefetch distance one chunk at no register cost.  Transform arithmetic, MFMA order per accumulator and the epilogue are
+// those of wino_kernel: outputs are bit-identical to it.
+template <int NT, bool ACT, int NP>                               // NP: staging pieces per thread (2, or 3 for the tallest patches)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 ? 3 : 2))) void wino_lds_kernel(const Wino g) {
+    constexpr int BNW = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // patch buffers during the loop, the epilogue's images afterwards
+#ifdef YH_WINO_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nwg = gridDim.x, orig = blockIdx.x;                  // XCD-aware bijective remap (see wino_kernel)
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tgrp = lin / g.ncol, colb = lin - tgrp * g.ncol;
+    const int n0 = colb * BNW;
+    const int rbk = tgrp / g.ncb, cbk = tgrp - rbk * g.ncb;
+    const int g0 = rbk * g.R, c0 = cbk * g.C;                      // first linear tile row (over B * TH) and first tile column
+    const int b0 = g0 / g.TH, ty0 = g0 - b0 * g.TH;
+    const int GT = g.B * g.TH;
+    const int Reff = min(g.R, GT - g0), Ceff = min(g.C, g.TW - c0);
+    const int cross = (g0 + Reff - 1) / g.TH - b0;                 // image boundaries inside the block: two extra patch rows each
+    const int rows_needed = 2 * Reff + 2 + 2 * cross;
+    const int PC = 2 * g.C + 2;
+
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+
+    int *const toff = (int *)(smem + g.toff_ofs);
+    int rdA[2], rdB[2];                                            // float offsets of patch rows ra / rb of this lane's tile, per column parity
+    {
+        int r = lr / g.C, c = lr - r * g.C;
+        const bool tv = r < Reff && c < Ceff;
+        const int grow = g0 + r, b = grow / g.TH, ty = grow - b * g.TH;
+        if (wave == 0 && lh == 0) toff[lr] = tv ? (b * g.H + 2 * ty) * g.W + 2 * (c0 + c) : -1;
+        const int prow0 = tv ? 2 * r + 2 * (b - b0) : 0;           // empty slots read tile 0's pixels (in bounds; results never stored)
+        if (!tv) c = 0;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            rdA[par] = (((lh * 2 + par) * g.plane) + (prow0 + ra) * g.PCh + c) * 4;
+            rdB[par] = (((lh * 2 + par) * g.plane) + (prow0 + rb) * g.PCh + c) * 4;
+        }
+    }
+    // staging plan, fixed for the kernel: piece = (k-quad, patch pixel) -> element offset in the input (-1: padding, stays zero;
+    // -2: no such piece) and float offset in a patch buffer
+    int gofs[NP], ldst[NP];
+    const int npieces = rows_needed * PC * 2;
+    const int qq = t & 1;                                          // the k-quad of every piece of this thread (256 is even)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int pid = t + 256 * k, pix = pid >> 1;
+        const int prow = pix / PC, pcol = pix - prow * PC;
+        int b, iy;
+        const int seg0 = 2 * (g.TH - ty0) + 2;                     // patch rows of the first image
+        if (prow < seg0) { b = b0; iy = 2 * ty0 - 1 + prow; }
+        else { const int pr = prow - seg0, sgm = pr / (2 * g.TH + 2); b = b0 + 1 + sgm; iy = pr - sgm * (2 * g.TH + 2) - 1; }
+        const int ix = 2 * c0 - 1 + pcol;
+        const bool ok = b < g.B && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        gofs[k] = pid < npieces ? (ok ? ((b * g.H + iy) * g.W + ix) * g.ldi + 4 * qq : -1) : -2;
+        ldst[k] = (((qq * 2 + (pcol & 1)) * g.plane) + prow * g.PCh + (pcol >> 1)) * 4;
+    }
+    const gfloat *const ing = yh_global(g.in);
+
+    const int kq4 = g.K >> 2;
+    const float *ub[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 32 + lr;
+        ub[j] = g.U + ((size_t)((4 * wave) * kq4 + lh) * g.ldu + (n < g.ldu ? n : 0)) * 4;
+    }
+    const size_t upos = (size_t)kq4 * g.ldu * 4;      // stride between positions
+    const size_t uchunk = (size_t)2 * g.ldu * 4;      // stride between chunks
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
-                T[0][j][r] = m0 + m1 + m2;
-                T[1][j][r] = m1 - m2 - m3;
-            }
-        auto put = [&](int id, const float (&v)[NT][16]) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *(f32x4 *)(smem + ((size_t)((id * NT + j) * 4 + q) * 64 + lane) * 4) = f32x4{v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]};
-        };
-        auto get = [&](int id, float (&v)[NT][16]) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 x = *(const f32x4 *)(smem + ((size_t)((id * NT + j) * 4 + q) * 64 + lane) * 4);
-                    v[j][4 * q] = x[0]; v[j][4 * q + 1] = x[1]; v[j][4 * q + 2] = x[2]; v[j][4 * q + 3] = x[3];
-                }
-        };
-        // images: 0 = T0[1], 1 = T1[0], 2 = T1[1], 3 = T2[0], 4 = T2[1], 5 = T3[0]
-        if (wave == 0) put(0, T[1]);
-        else if (wave == 1) { put(1, T[0]); put(2, T[1]); }
-        else if (wave == 2) { put(3, T[0]); put(4, T[1]); }
-        else put(5, T[0]);
-        __syncthreads();
-        float Y[NT][16], L1[NT][16], L2[NT][16];
-        if (wave == 0) {            // row 0, column 0: (T0[0] + T1[0]) + T2[0]
-            get(1, L1); get(3, L2);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Y[j][r] = (T[0][j][r] + L1[j][r]) + L2[j][r];
-        } else if (wave == 1) {     // row 0, column 1: (T0[1] + T1[1]) + T2[1]
-            get(0, L1); get(4, L2);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] + T[1][j][r]) + L2[j][r];
-        } else if (wave == 2) {     // row 1, column 0: (T1[0] - T2[0]) - T3[0]
-            get(1, L1); get(5, L2);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - T[0][j][r]) - L2[j][r];
-        } else {                    // row 1, column 1: (T1[1] - T2[1]) - T3[1]
-            get(2, L1); get(4, L2);
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - L2[j][r]) - T[1][j][r];
-        }
-        // register r of this lane = tile (r & 3) + 8 (r >> 2) + 4 lh of the group: four consecutive offsets per 16-byte read
-        const int *toff = (const int *)(smem + IMG_FLOATS);
-        int tp[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const i32x4 x = *(const i32x4 *)(toff + 8 * q + 4 * lh);
-            tp[4 * q] = x[0]; tp[4 * q + 1] = x[1]; tp[4 * q + 2] = x[2]; tp[4 * q + 3] = x[3];
-        }
-        const int pc = (wave >> 1) * g.W + (wave & 1);
-        gfloat *const outg = yh_global(g.out);
-        const bool whole = tile0 + TPB <= g.ntiles && n0 + BNW <= g.N;       // wave-uniform
-        float cs[NT], cq[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + 32 * j + lr;
-            const bool nok = n < g.N;
-            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-            cs[j] = cq[j] = 0.f;
-            if (whole) {
-                if (!g.accumulate) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = Y[j][r] + bias;
-                        outg[(unsigned)((tp[r] + pc) * g.ldo + n)] = v;
-                        cs[j] += v;
-                        cq[j] += v * v;
-                    }
-                } else {
-                    float old[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) old[r] = outg[(unsigned)((tp[r] + pc) * g.ldo + n)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = Y[j][r] + bias + old[r];
-                        outg[(unsigned)((tp[r] + pc) * g.ldo + n)] = v;
-                        cs[j] += v;
-                        cq[j] += v * v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (nok && tp[r] >= 0) {
-                        gfloat *o = outg + (unsigned)((tp[r] + pc) * g.ldo + n);
-                        float v = Y[j][r] + bias;
-                        if (g.accumulate) v += *o;
-                        *o = v;
-                        cs[j] += v;
-                        cq[j] += v * v;
-                    }
-            }
-        }
-        if (g.stats) {
-            float *red = smem + IMG_FLOATS + 32;                          // [4 waves][BNW][2]
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float s = cs[j] + __shfl_xor(cs[j], 32), q = cq[j] + __shfl_xor(cq[j], 32);
-                if (lh == 0) { red[(wave * BNW + 32 * j + lr) * 2] = s; red[(wave * BNW + 32 * j + lr) * 2 + 1] = q; }
-            }
-            __syncthreads();
-            if (t < BNW && n0 + t < g.N) {
-                const float a0 = (red[t * 2] + red[(BNW + t) * 2]) + (red[(2 * BNW + t) * 2] + red[(3 * BNW + t) * 2]);
-                const float a1 = (red[t * 2 + 1] + red[(BNW + t) * 2 + 1]) + (red[(2 * BNW + t) * 2 + 1] + red[(3 * BNW + t) * 2 + 1]);
-                g.stats[((size_t)tgrp * 2 + 0) * g.N + n0 + t] = a0;
-                g.stats[((size_t)tgrp * 2 + 1) * g.N + n0 + t] = a1;
-            }
-        }
-#ifdef YH_WINO_STAMPS
-        if (g.dbg && t == 0) {
-            unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
-            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
-        }
-#endif
-        return;
-    }
+            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
 
-    // ---- output transform, general form.  nu-contraction (lane-local): s0 = m0+m1+m2, s1 = m1-m2-m3 -------------------
-    float *S = smem;                           // [xi 4][j 2][tile 32][ch BNW]
+    // the producer's scale / shift of the chunk's 8 channels: wave-uniform, so they travel through the scalar cache into SGPRs
+    // (written by an earlier kernel: coherent at the launch boundary) and cost no vector register while the MFMAs run
+    typedef const __attribute__((address_space(4))) f32x4 cf32x4;
+    f32x4 csc0, csc1, csh0, csh1, cg0, cg1;
+    // UNCONDITIONAL loads (padding / absent pieces re-read element 0 of the chunk and are zeroed / dropped at the store): a load
+    // under a branch makes every later counted s_waitcnt a vmcnt(0), which would wait for the prefetches in front of the MFMAs
+    auto stage_load = [&](int c, f32x4 (&sr)[NP]) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float m0 = acc[0][j][r], m1 = acc[1][j][r], m2 = acc[2][j][r], m3 = acc[3][j][r];
-            S[((wave * 2 + 0) * TPB + row) * BNW + j * 32 + lr] = m0 + m1 + m2;
-            S[((wave * 2 + 1) * TPB + row) * BNW + j * 32 + lr] = m1 - m2 - m3;
+        for (int k = 0; k < NP; ++k) {
+#if defined(YH_WL_ABL) && (YH_WL_ABL & 2)
+            sr[k] = f32x4{(float)c, 1.f, 2.f, 3.f};
+#else
+            sr[k] = *(const YH_GLOBAL f32x4 *)(ing + (gofs[k] > 0 ? gofs[k] : 0) + c * KC);
+#endif
         }
-    __syncthreads();
-    // xi-contraction + store: thread = (channel, tile group); 256 / BNW tile groups
-    constexpr int TG = 256 / BNW;
-    const int ch = t % BNW, tgp = t / BNW, n = n0 + ch;
-    const bool nok = n < g.N;
-    const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-    float csum = 0.f, csq = 0.f;
-    for (int it = 0; it < TPB / TG; ++it) {
-        const int tl = tgp + TG * it, tg = tile0 + tl;
-        if (tg >= g.ntiles) break;
-        int b = fdiv(tg, g.tpi_magic, g.tpi_shift), r = tg - b * g.TPI;
-        int ty = fdiv(r, g.tw_magic, g.tw_shift), tx = r - ty * g.TW;
-        if (!nok) continue;
-        float s[4][2];
+    };
+    auto coef_load = [&](int c) {
+        if constexpr (ACT) {
+            cf32x4 *ps = (cf32x4 *)(g.icoef + c * KC), *ph = (cf32x4 *)(g.icoef + g.icoef_ld + c * KC),
+                   *pg = (cf32x4 *)(g.icoef + 2 * g.icoef_ld + c * KC);
+            csc0 = ps[0]; csc1 = ps[1]; csh0 = ph[0]; csh1 = ph[1]; cg0 = pg[0]; cg1 = pg[1];
+        }
+    };
+    auto stage_store = [&](float *buf, const f32x4 (&sr)[NP]) {
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
+        for (int k = 0; k < NP; ++k) {
+            f32x4 v = sr[k];
+            if constexpr (ACT) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) s[xi][j] = S[((xi * 2 + j) * TPB + tl) * BNW + ch];
-        float *o = g.out + ((size_t)(b * g.H + 2 * ty) * g.W + 2 * tx) * g.ldo + n;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float y0 = s[0][j] + s[1][j] + s[2][j] + bias;
-            float y1 = s[1][j] - s[2][j] - s[3][j] + bias;
-            float *o0 = o + (size_t)j * g.ldo, *o1 = o0 + (size_t)g.W * g.ldo;
-            if (g.accumulate) { y0 += *o0; y1 += *o1; }
-            if (g.act | g.up2 | (g.res != nullptr)) {          // inference form (uniform branch)
-                if (g.act) { y0 = y0 * yh_sigmoid(y0); y1 = y1 * yh_sigmoid(y1); }
-                const size_t p0 = (size_t)(b * g.H + 2 * ty) * g.W + 2 * tx + j;
-                if (g.res) { y0 += g.res[p0 * g.ldr + n]; y1 += g.res[(p0 + g.W) * g.ldr + n]; }
-                if (g.up2) {
-                    const size_t rs = (size_t)(2 * g.W) * g.ldo;
-                    float *u0 = g.out + (((size_t)b * 2 * g.H + 4 * ty) * 2 * g.W + 4 * tx + 2 * j) * g.ldo + n;
-                    float *u1 = u0 + 2 * rs;
-                    u0[0] = y0; u0[g.ldo] = y0; u0[rs] = y0; u0[rs + g.ldo] = y0;
-                    u1[0] = y1; u1[g.ldo] = y1; u1[rs] = y1; u1[rs + g.ldo] = y1;
-                    continue;
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = yh_prologue(v[e], qq ? csc1[e] : csc0[e], qq ? csh1[e] : csh0[e], qq ? cg1[e] : cg0[e]);
                 }
             }
-            *o0 = y0; *o1 = y1;
-            csum += y0 + y1;
-            csq += y0 * y0 + y1 * y1;
+            if (gofs[k] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};        // padding is zero AFTER the activation
+#if defined(YH_WL_ABL) && (YH_WL_ABL & 4)
+            asm volatile("" :: "v"(v));
+#else
+            if (gofs[k] != -2) *(f32x4 *)(buf + ldst[k]) = v;
+#endif
         }
-    }
-    if (g.stats) {
-        float *red = smem + 4 * 2 * TPB * BNW;   // [TG][BNW][2]
-        red[(tgp * BNW + ch) * 2 + 0] = csum;
-        red[(tgp * BNW + ch) * 2 + 1] = csq;
-        __syncthreads();
-        if (tgp == 0 && nok) {                   // ch == t: the thread that looked its column up
-            float a0 = 0.f, a1 = 0.f;
+    };
+
+    // Software pipeline over chunks of 8 input channels (nchunks is even).  In iteration c a wave
+    //   issues the piece loads of chunk c + 2 (two register sets: the HBM latency has two chunks of MFMAs to hide behind),
+    //   runs MFMA groups 0, 1 (transform rows' positions nu = 0, 1; each group re-loads its weight fragments for chunk c + 1 in place),
+    //   applies the activation to the pieces of chunk c + 1 and parks them in the other patch buffer, BARRIER,
+    //   issues the eight operand reads of chunk c + 1, runs group 2 over their latency, transforms (V[0..2] of chunk c + 1 overwrite
+    //   the dead ones), runs group 3, finishes V[3]:
+    // the matrix pipe sees back-to-back MFMAs across the chunk boundary from a SINGLE wave (the first form of this loop relied on the
+    // second resident workgroup to fill ~2 900 idle cycles per chunk: 2.4x the MFMA time whenever a workgroup ran alone on its CU).
+    const int nchunks = g.K / KC, last = nchunks - 1;
+    f32x4 u[4][NT], sA[NP], sB[NP], V[4], tt[4], d[2][4];
+    auto group = [&](int v, int cn) {
 #pragma unroll
-            for (int w = 0; w < TG; ++w) { a0 += red[(w * BNW + t) * 2]; a1 += red[(w * BNW + t) * 2 + 1]; }
-            g.stats[((size_t)tgrp * 2 + 0) * g.N + n] = a0;
-            g.stats[((size_t)tgrp * 2 + 1) * g.N + n] = a1;
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], u[v][j][e], acc[v][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(YH_WL_ABL) && (YH_WL_ABL & 16))
+#pragma unroll
+        for (int j = 0; j < NT; ++j) u[v][j] = *(const f32x4 *)(ub[j] + v * upos + cn * uchunk);   // next chunk, in place
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_patch = [&](const float *buf) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#if defined(YH_WL_ABL) && (YH_WL_ABL & 8)
+            d[0][cc] = V[cc] + 1.f; d[1][cc] = V[cc] - 1.f;
+#else
+            d[0][cc] = *(const f32x4 *)(buf + rdA[cc & 1] + 4 * (cc >> 1));
+            d[1][cc] = *(const f32x4 *)(buf + rdB[cc & 1] + 4 * (cc >> 1));
+#endif
         }
+    };
+    auto iteration = [&](int c, f32x4 (&sNext)[NP], f32x4 (&sFar)[NP]) {
+        const int c1 = c + 1 < last ? c + 1 : last, c2 = c + 2 < last ? c + 2 : last;     // clamped: the tail re-loads, nothing branches
+        float *const nxt = smem + ((c & 1) ^ 1) * g.bufsz;
+        stage_load(c2, sFar);
+        coef_load(c1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, c1);
+        group(1, c1);
+        if (c < last) stage_store(nxt, sNext);                     // wave-uniform branch around LDS stores only
+#if !(defined(YH_WL_ABL) && (YH_WL_ABL & 1))
+        __syncthreads();                                           // chunk c + 1 is parked; chunk c - 1's buffer is free again
+#endif
+        read_patch(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        group(2, c1);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) tt[cc] = d[0][cc] + sg * d[1][cc];
+        V[0] = tt[0] - tt[2];
+        V[1] = tt[1] + tt[2];
+        V[2] = tt[2] - tt[1];
+        __builtin_amdgcn_sched_barrier(0);
+        group(3, c1);
+        V[3] = tt[1] - tt[3];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    stage_load(0, sA);
+    coef_load(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) u[v][j] = *(const f32x4 *)(ub[j] + v * upos);
+    stage_store(smem, sA);
+    stage_load(last > 0 ? 1 : 0, sA);
+    __syncthreads();
+    read_patch(smem);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) tt[cc] = d[0][cc] + sg * d[1][cc];
+    V[0] = tt[0] - tt[2];
+    V[1] = tt[1] + tt[2];
+    V[2] = tt[2] - tt[1];
+    V[3] = tt[1] - tt[3];
+#ifdef YH_WINO_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int c = 0; c < nchunks; c += 2) {
+        iteration(c, sA, sB);
+        iteration(c + 1, sB, sA);
     }
+    __syncthreads();                                               // every wave has read its last operands: the epilogue reuses the buffers
+#ifdef YH_WINO_STAMPS
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
+    wino_epilogue<NT>(g, acc, smem, toff, Reff * Ceff == TPB, tgrp, n0);
 #ifdef YH_WINO_STAMPS
     if (g.dbg && t == 0) {
         unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
@@ -855,7 +1096,7 @@ template <int NT, int PIPE>
 int launch_nt(Wino &g, hipStream_t st) {
     constexpr int BNW = 32 * NT;
     g.ncol = cdiv(g.N, BNW);
-    constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2) * sizeof(float);
+    constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2 + TPB) * sizeof(float);
     if (int rc = yh_ensure_dyn_smem((const void *)wino_kernel<NT, PIPE>, smem)) return rc;
 #ifdef YH_WINO_STAMPS
     static unsigned long long *dbgbuf = nullptr;
@@ -906,6 +1147,121 @@ int launch_wino(Wino &g, hipStream_t st) {
     const int pipe = force ? force : (cdiv(g.ntiles, TPB) >= 800 ? 1 : 2);
     if (g.N <= 32) return pipe == 3 ? launch_nt<1, 3>(g, st) : pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
     return pipe == 3 ? launch_nt<2, 3>(g, st) : pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
+}
+
+
+// ---- LDS-staged kernel: block geometry ------------------------------------------------------------------------------------
+// R x C tiles per workgroup (R C <= 32) over B*TH linear tile rows x TW tile columns: the fewest workgroups (= the fewest MFMA
+// tile slots), then the smallest patch.  PCh (half-row stride of the patch planes, in 16-byte slots) is searched so that the 16
+// lanes ds_read_b128 serves per LDS cycle ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: MI355X_MICROARCH.md, LDS) hit 16
+// different slots of the 256-byte bank row; the plane stride is padded to 2 mod 8 slots, which makes the staging ds_write_b128
+// (8 consecutive lanes = 4 consecutive pixels x 2 k-quads) conflict-free as well.
+struct WinoGeom {
+    int R, C, PCh, PR, plane, bufsz, nrb, ncb;
+};
+static int wino_read_conflicts(int R, int C, int PCh) {
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int worst = 0;
+    for (int gi = 0; gi < 2; ++gi) {
+        int cnt[16] = {0};
+        bool zero_seen = false;
+        for (int k = 0; k < 16; ++k) {
+            int l = grp[gi][k];
+            if (l >= R * C) l = 0;                  // empty slots read tile 0 (identical addresses broadcast)
+            if (l == 0) { if (zero_seen) continue; zero_seen = true; }
+            const int r = l / C, c = l - r * C;
+            ++cnt[(2 * r * PCh + c) & 15];
+        }
+        for (int k = 0; k < 16; ++k) worst = cnt[k] > worst ? cnt[k] : worst;
+    }
+    return worst;
+}
+static bool wino_lds_geom(int B, int TH, int TW, WinoGeom &o) {
+    long best_cost = -1;
+    const int GT = B * TH;
+    for (int maxp = 512; maxp <= 768 && best_cost < 0; maxp += 256)     // two pieces per thread if any block shape allows it
+    for (int C = 1; C <= 32 && C <= TW; ++C) {
+        int R = 32 / C;
+        if (R > GT) R = GT;
+        const int maxcross = R > 1 ? (R - 1 + TH - 1) / TH : 0;
+        const int PR = 2 * R + 2 + 2 * maxcross, PC = 2 * C + 2;
+        if (PR * PC * 2 > maxp) continue;           // 16-byte pieces per thread: two, three at most
+        const int nrb = cdiv(GT, R), ncb = cdiv(TW, C);
+        const long cost = (long)nrb * ncb * 4096 + PR * PC;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            o.R = R; o.C = C; o.PR = PR; o.nrb = nrb; o.ncb = ncb;
+        }
+    }
+    if (best_cost < 0) return false;
+    int bestp = o.C + 1, bestw = 1 << 30;
+    for (int p = o.C + 1; p < o.C + 1 + 16; ++p) {
+        const int w = wino_read_conflicts(o.R, o.C, p);
+        if (w < bestw) { bestw = w; bestp = p; }
+    }
+    o.PCh = bestp;
+    o.plane = o.PR * o.PCh;
+    while ((o.plane & 7) != 2) ++o.plane;
+    o.bufsz = 4 * o.plane * 4;
+    return true;
+}
+
+template <int NT, bool ACT, int NP>
+int launch_lds_np(Wino &g, const WinoGeom &gm, hipStream_t st) {
+    constexpr int BNW = 32 * NT;
+    g.ncol = cdiv(g.N, BNW);
+    const int epi = 4 * 2 * TPB * BNW + 256 * 2;
+    g.toff_ofs = 2 * gm.bufsz > epi ? 2 * gm.bufsz : epi;
+    const size_t smem = (size_t)(g.toff_ofs + TPB) * sizeof(float);
+    YH_REQUIRE(smem <= 80 * 1024, "conv_wino (LDS-staged): patch buffers exceed the budget of two workgroups per CU");
+    if (int rc = yh_ensure_dyn_smem((const void *)wino_lds_kernel<NT, ACT, NP>, smem)) return rc;
+#ifdef YH_WINO_STAMPS
+    static unsigned long long *dbgbuf = nullptr;
+    const int nwg_dbg = gm.nrb * gm.ncb * g.ncol;
+    if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
+    g.dbg = getenv("YH_WINO_DBG") && (size_t)nwg_dbg * 48 <= ((size_t)1 << 24) ? dbgbuf : nullptr;
+#endif
+    hipLaunchKernelGGL((wino_lds_kernel<NT, ACT, NP>), dim3(gm.nrb * gm.ncb * g.ncol), dim3(256), smem, st, g);
+    YH_CHECK_LAUNCH("wino_lds");
+#ifdef YH_WINO_STAMPS
+    if (g.dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)nwg_dbg * 6);
+        (void)hipMemcpy(h.data(), g.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double a = 0, b = 0, c = 0, rt = 0; unsigned long long lo = ~0ull, hi = 0;
+        for (int i = 0; i < nwg_dbg; ++i) {
+            a += (double)(h[6 * i + 1] - h[6 * i]); b += (double)(h[6 * i + 2] - h[6 * i + 1]); c += (double)(h[6 * i + 3] - h[6 * i + 2]);
+            rt += (double)(h[6 * i + 5] - h[6 * i + 4]);
+            if (h[6 * i + 4] < lo) lo = h[6 * i + 4];
+            if (h[6 * i + 5] > hi) hi = h[6 * i + 5];
+        }
+        const double mf = (double)(g.K / 8) * 16 * NT * 64;
+        fprintf(stderr, "[wino lds stamps] NT %d ACT %d K %d N %d R %d C %d wgs %d: setup %.0f, loop %.0f (MFMA issue floor %.0f), epilogue %.0f cycles per workgroup = %.2f us (clock %.2f GHz); span %.1f us\n",
+                NT, (int)ACT, g.K, g.N, g.R, g.C, nwg_dbg, a / nwg_dbg, b / nwg_dbg, mf, c / nwg_dbg, rt / nwg_dbg / 100.0, (a + b + c) / rt * 0.1, (double)(hi - lo) / 100.0);
+    }
+#endif
+    return 0;
+}
+template <int NT, bool ACT>
+int launch_lds_nt(Wino &g, const WinoGeom &gm, hipStream_t st) {
+    return gm.PR * (2 * gm.C + 2) * 2 <= 512 ? launch_lds_np<NT, ACT, 2>(g, gm, st) : launch_lds_np<NT, ACT, 3>(g, gm, st);
+}
+
+int launch_wino_lds(Wino &g, hipStream_t st) {
+    YH_REQUIRE(g.H % 2 == 0 && g.W % 2 == 0, "conv_wino: H and W must be even");
+    YH_REQUIRE(g.K % (2 * KC) == 0 && g.ldi % 4 == 0 && (((uintptr_t)g.in | (uintptr_t)g.U) & 15) == 0 && g.ldu >= g.N,
+               "conv_wino: K must be a multiple of 16, buffers 16-byte addressable");
+    YH_REQUIRE(!g.icoef || ((((uintptr_t)g.icoef) & 15) == 0 && g.icoef_ld % 4 == 0 && g.icoef_ld >= g.K),
+               "conv_wino: the input prologue table must be 16-byte aligned with a stride that is a multiple of 4");
+    YH_REQUIRE((int64_t)g.B * g.H * g.W * g.ldi < (1ll << 31) && (int64_t)g.B * g.H * g.W * g.ldo * (g.up2 ? 4 : 1) < (1ll << 31),
+               "conv_wino: tensors exceed 32-bit element offsets");
+    g.TW = g.W / 2; g.TH = g.H / 2; g.TPI = g.TH * g.TW; g.ntiles = g.B * g.TPI;
+    WinoGeom gm{};
+    YH_REQUIRE(wino_lds_geom(g.B, g.TH, g.TW, gm), "conv_wino: no block geometry for this shape");
+    g.R = gm.R; g.C = gm.C; g.ncb = gm.ncb; g.PCh = gm.PCh; g.plane = gm.plane; g.bufsz = gm.bufsz;
+    if (g.icoef) return g.N <= 32 ? launch_lds_nt<1, true>(g, gm, st) : launch_lds_nt<2, true>(g, gm, st);
+    return g.N <= 32 ? launch_lds_nt<1, false>(g, gm, st) : launch_lds_nt<2, false>(g, gm, st);
 }
 
 }  // namespace
@@ -1062,4 +1418,29 @@ extern "C" int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub,
     g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
     g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
     return launch_wino(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_wino_lds_blocks(int B, int H, int W) {
+    WinoGeom gm{};
+    if (H <= 0 || W <= 0 || B <= 0 || (H | W) & 1 || !wino_lds_geom(B, H / 2, W / 2, gm)) return -1;
+    return gm.nrb * gm.ncb;
+}
+
+extern "C" int yh_conv_wino_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *U, int ldu,
+                                    const float *bias, float *y, int ldy, float *bn_partials, int B, int H, int W, int Cin, int Cout,
+                                    void *stream) {
+    YH_REQUIRE(x && U && y && B > 0 && H > 0 && W > 0 && ldx >= Cin && ldy >= Cout, "conv_wino_fwd_act: bad argument");
+    Wino g{};
+    g.in = x; g.U = U; g.bias = bias; g.out = y; g.stats = bn_partials; g.icoef = icoef; g.icoef_ld = icoef_ld;
+    g.ldi = ldx; g.ldu = ldu; g.ldo = ldy; g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = Cout; g.accumulate = 0;
+    return launch_wino_lds(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_wino_bwd_data_lds(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
+                                         int W, int Cin, int Cout, int accumulate, void *stream) {
+    YH_REQUIRE(dy && Ub && dx && B > 0 && H > 0 && W > 0 && lddy >= Cout && lddx >= Cin, "conv_wino_bwd_data_lds: bad argument");
+    Wino g{};
+    g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
+    g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
+    return launch_wino_lds(g, (hipStream_t)stream);
 }
