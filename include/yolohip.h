@@ -190,22 +190,46 @@ int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const flo
                      float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
 int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                           int W, int Cin, int Cout, int accumulate, void *stream);
-/* The same two passes with the input patch of a 2-D block of tiles staged once through LDS (round 4): K % 16 == 0, bit-identical
- * results.  icoef (or NULL): the input prologue table [scale | shift | gate], three rows of Cin floats icoef_ld floats apart -- the
+/* ---- input prologue (round 4) ----------------------------------------------------------------------------------------------
+ * Every forward / weight-gradient entry point below has an `_act` form taking the prologue table of its x operand: icoef =
+ * three rows [scale | shift | gate] of Cin floats, icoef_ld floats apart (NULL: the plain entry point).  The kernel reads the
+ * PRODUCER's raw convolution output and uses z = x * scale[k] + shift[k], silu(z) where gate[k] != 0, as its input -- the
+ * producer's BatchNorm + SiLU applied while the operand is staged, zero padding after the activation, so the normalised tensor
+ * never exists in memory (train.py:253-265 executed at the consumer).  Same results as the plain entry point on the
+ * materialised activation (same expression, same hardware exp / rcp as yh_bn_silu_fwd). */
+int yh_conv_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wf, int ldwf, const float *bias, float *y, int ldy,
+                    float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
+int yh_conv_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                           int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k, int s, void *stream);
+int yh_conv_bwd_weight_prologue_ok(int B, int Hi, int Wi, int Cin, int Cout, int k, int s);
+int yh_conv_pw_prologue_ok(int64_t M, int Cin, int Cout);       /* the streaming and tiled pointwise forward kernels have a prologue */
+int yh_conv_pw_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias, float *y, int ldy,
+                       float *bn_partials, int64_t M, int Cin, int Cout, void *stream);
+int yh_conv_pw_fwd2_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias1, float *y1,
+                        int ldy1, float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2, int cout2,
+                        int64_t M, int Cin, void *stream);
+int yh_conv_pw_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                              int64_t ws_floats, int64_t M, int Cin, int Cout, void *stream);
+int yh_conv_narrow_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *w, int ldw, const float *bias, float *y, int ldy,
+                       float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, void *stream);      /* 16-channel inputs */
+int yh_conv_narrow_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *dbias,
+                                  float *ws, int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream);
+/* Forward with an input prologue.  icoef (or NULL = yh_conv_wino_fwd): the input prologue table [scale | shift | gate], three rows of Cin floats icoef_ld floats apart -- the
  * PRODUCER's BatchNorm + SiLU fused into the staging: the kernel reads the producer's raw convolution output x and uses
  * z = x * scale[k] + shift[k], silu(z) where gate[k] != 0, as its input; zero padding is applied after the activation, so the
  * normalised tensor never exists in memory (replaces the ConvBlock.forward hand-over, train.py:253-265).
- * bn_partials: [yh_conv_wino_lds_blocks][2][Cout]. */
-int yh_conv_wino_lds_blocks(int B, int H, int W);
+ * bn_partials: [yh_conv_wino_blocks][2][Cout]. */
 int yh_conv_wino_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *U, int ldu, const float *bias,
                          float *y, int ldy, float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
-int yh_conv_wino_bwd_data_lds(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H, int W, int Cin,
-                              int Cout, int accumulate, void *stream);
 /* Backward-weight in the Winograd domain (Cin % 32 == 0, Cout % 32 == 0, even H, W): dw (OIHW) = the same sum as
  * yh_conv_bwd_weight for k = 3, s = 1, deterministic (fixed-order reduction of per-workgroup [9][Cin][Cout] slabs
  * through ws, ws_floats >= yh_conv_wino_bwd_weight_ws(...)). */
 int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
                             int B, int H, int W, int Cin, int Cout, void *stream);
+/* The same with the input prologue applied to x (see yh_conv_wino_fwd_act): the weight gradient of a convolution whose input
+ * activation was never materialised. */
+int yh_conv_wino_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                                int64_t ws_floats, int B, int H, int W, int Cin, int Cout, void *stream);
 int64_t yh_conv_wino_bwd_weight_ws(int B, int H, int W, int Cin, int Cout);
 /* Backward-weight of a pointwise (1x1, stride 1) convolution over M = B*H*W pixels: dw[co][ci] = sum_p x[p][ci] dy[p][co],
  * MFMA operands loaded straight into registers (no LDS in the loop), deterministic slab reduction through ws
@@ -256,6 +280,11 @@ int64_t yh_colsum_ws(int64_t M, int C);
 int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
                    int64_t *num_batches_tracked, void *stream);
+/* The same, and additionally the rows `scale` / `shift` of a CONSUMER-side input-prologue table (xscale / xshift, both or
+ * neither): when the activation of this layer is never materialised, the kernels that read it apply it (yh_conv_*_act). */
+int yh_bn_finalize_x(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, float momentum, float eps, float *coef, int C, int64_t *num_batches_tracked, float *xscale,
+                     float *xshift, void *stream);
 /* Inference coefficients from running statistics (BN folded to scale/shift). */
 int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
                     float eps, float *coef, int C, void *stream);
@@ -265,6 +294,10 @@ int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_
  * because `out` may be a channel slice of the concat buffer. */
 int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
                    int ldo, int64_t M, int C, int H, int W, int upsample, void *stream);
+/* The same with a residual that was never materialised: `residual` is its producer's raw convolution output, rcoef its
+ * prologue table rows [scale | shift | gate], rcoef_ld floats apart. */
+int yh_bn_silu_fwd_res(const float *y, int ldy, const float *coef, const float *residual, int ldr, const float *rcoef, int rcoef_ld,
+                       float *out, int ldo, int64_t M, int C, int H, int W, int upsample, void *stream);
 /* Backward stage 1: per-channel partial sums of dz and dz*xhat where dz = da*silu'(z);
  * da is read with a 2x2 sum when `upsample`.  partials: [nblk][2][C], nblk = yh_bn_bwd_blocks(M). */
 int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef, float *partials,

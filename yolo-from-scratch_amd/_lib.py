@@ -64,10 +64,18 @@ _SIGS = {
     "yh_wino_weights_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_wino_blocks": (i32, [i32, i32, i32]),
     "yh_conv_wino_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
-    "yh_conv_wino_lds_blocks": (i32, [i32, i32, i32]),
     "yh_conv_wino_fwd_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
-    "yh_conv_wino_bwd_data_lds": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_fwd_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_bwd_weight_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_bwd_weight_prologue_ok": (i32, [i32, i32, i32, i32, i32, i32, i32]),
+    "yh_conv_pw_prologue_ok": (i32, [i64, i32, i32]),
+    "yh_conv_pw_fwd_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i64, i32, i32, c_fp]),
+    "yh_conv_pw_fwd2_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, c_fp]),
+    "yh_conv_pw_bwd_weight_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i64, i32, i32, c_fp]),
+    "yh_conv_narrow_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_narrow_bwd_weight_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_wino_bwd_weight_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_wino_bwd_weight_ws": (i64, [i32, i32, i32, i32, i32]),
     "yh_conv_fwd_fused_splitk": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                        c_fp]),
@@ -99,6 +107,8 @@ _SIGS = {
     "yh_colsum": (i32, [c_fp, i32, i64, i32, c_fp, c_fp, c_fp]),
     "yh_colsum_ws": (i64, [i64, i32]),
     "yh_bn_finalize": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp, c_fp]),
+    "yh_bn_finalize_x": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp, c_fp, c_fp, c_fp]),
+    "yh_bn_silu_fwd_res": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "yh_bn_eval_coef": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),
     "yh_bn_silu_fwd": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "yh_bn_silu_bwd_reduce": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),

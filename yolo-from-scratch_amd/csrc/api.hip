@@ -37,25 +37,26 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_PACK_WEIGHTS:
             return yh_pack_weights((const float *)p[0], (float *)p[1], (float *)p[2], i[0], i[1], i[2], i[3], i[4], i[5], st);
         case YH_OP_CONV_FWD:
-            return yh_conv_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3],
-                               i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
+            return yh_conv_fwd_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (const float *)p[2],
+                                   (float *)p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
         case YH_OP_CONV_BWD_DATA:
             return yh_conv_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
                                     i[5], i[6], i[7], i[8], i[9], i[10], st);
         case YH_OP_CONV_BWD_WEIGHT:
-            return yh_conv_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
-                                      o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
+            return yh_conv_bwd_weight_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (float *)p[2],
+                                          (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
         case YH_OP_COLSUM:
             return yh_colsum((const float *)p[0], i[0], o.l[0], i[1], (float *)p[1], (float *)p[2], st);
-        case YH_OP_BN_FINALIZE:
-            return yh_bn_finalize((const float *)p[0], i[0], o.l[0], (const float *)p[1], (const float *)p[2],
-                                  (float *)p[3], (float *)p[4], f[0], f[1], (float *)p[5], i[1], (int64_t *)p[6], st);
+        case YH_OP_BN_FINALIZE:        /* p[7], p[8]: scale / shift rows of a consumer-side prologue table, or NULL */
+            return yh_bn_finalize_x((const float *)p[0], i[0], o.l[0], (const float *)p[1], (const float *)p[2],
+                                    (float *)p[3], (float *)p[4], f[0], f[1], (float *)p[5], i[1], (int64_t *)p[6], (float *)p[7],
+                                    (float *)p[8], st);
         case YH_OP_BN_EVAL_COEF:
             return yh_bn_eval_coef((const float *)p[0], (const float *)p[1], (const float *)p[2], (const float *)p[3], f[0],
                                    (float *)p[4], i[0], st);
-        case YH_OP_BN_SILU_FWD:
-            return yh_bn_silu_fwd((const float *)p[0], i[0], (const float *)p[1], (const float *)p[2], i[1], (float *)p[3],
-                                  i[2], o.l[0], i[3], i[4], i[5], i[6], st);
+        case YH_OP_BN_SILU_FWD:        /* p[4] / i[7]: prologue table of a residual that was never materialised, or NULL */
+            return yh_bn_silu_fwd_res((const float *)p[0], i[0], (const float *)p[1], (const float *)p[2], i[1], (const float *)p[4], i[7],
+                                      (float *)p[3], i[2], o.l[0], i[3], i[4], i[5], i[6], st);
         case YH_OP_BN_SILU_BWD_REDUCE:
             return yh_bn_silu_bwd_reduce((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
                                          (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], st);
@@ -77,18 +78,19 @@ static int run_one(const yh_op &o, void *st) {
             return yh_add_int64((int64_t *)p[0], o.l[0], st);
         case YH_OP_WINO_WEIGHTS_MULTI:
             return yh_wino_weights_multi(p[0], i[0], st);
+        /* convolution records carry the input-prologue table of their x operand in p[10] (NULL: plain input), its row stride in i[17] */
         case YH_OP_CONV_WINO_FWD:
-            return yh_conv_wino_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3],
-                                    i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], st);
+            return yh_conv_wino_fwd_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (const float *)p[2],
+                                        (float *)p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], st);
         case YH_OP_CONV_WINO_BWD_DATA:
             return yh_conv_wino_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4],
                                          i[5], i[6], i[7], i[8], st);
         case YH_OP_CONV_WINO_BWD_WEIGHT:
-            return yh_conv_wino_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
-                                           o.l[0], i[2], i[3], i[4], i[5], i[7], st);
+            return yh_conv_wino_bwd_weight_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (float *)p[2],
+                                               (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], i[7], st);
         case YH_OP_CONV_PW_BWD_WEIGHT:      /* same argument slots as YH_OP_CONV_BWD_WEIGHT */
-            return yh_conv_pw_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[3],
-                                         o.l[0], (int64_t)i[2] * i[3] * i[4], i[5], i[7], st);
+            return yh_conv_pw_bwd_weight_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (float *)p[2],
+                                             (float *)p[3], o.l[0], (int64_t)i[2] * i[3] * i[4], i[5], i[7], st);
         case YH_OP_CONV_STEM_FWD:           /* retired (the first layer runs on narrow_conv_kernel); the enum slot stays for ABI stability */
             yh_set_error("yh_run: YH_OP_CONV_STEM_FWD was retired in round 3");
             return YH_E_UNSUPPORTED;
@@ -98,28 +100,31 @@ static int run_one(const yh_op &o, void *st) {
             return yh_conv_bwd_data_s2m((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4], i[5],
                                         i[6], i[7], i[10], st);
         case YH_OP_CONV_PW_FWD2:            /* p: x, wq, bias1, y1, part1, bias2, y2, part2;  i: ldx, ldw, ldy1, B, H, W, Cin, cout1, ldy2, cout2 */
-            return yh_conv_pw_fwd2((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
-                                   (float *)p[4], i[7], (const float *)p[5], (float *)p[6], i[8], (float *)p[7], i[9],
-                                   (int64_t)i[3] * i[4] * i[5], i[6], st);
+            return yh_conv_pw_fwd2_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (const float *)p[2],
+                                       (float *)p[3], i[2], (float *)p[4], i[7], (const float *)p[5], (float *)p[6], i[8], (float *)p[7], i[9],
+                                       (int64_t)i[3] * i[4] * i[5], i[6], st);
         case YH_OP_PW_PACK_MULTI:
             return yh_pw_pack_multi(p[0], i[0], st);
         case YH_OP_CONV_PW_FWD:             /* same argument slots as YH_OP_CONV_FWD */
-            return yh_conv_pw_fwd((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
-                                  (float *)p[4], (int64_t)i[3] * i[4] * i[5], i[6], i[7], st);
+            return yh_conv_pw_fwd_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (const float *)p[2],
+                                      (float *)p[3], i[2], (float *)p[4], (int64_t)i[3] * i[4] * i[5], i[6], i[7], st);
         case YH_OP_CONV_PW_BWD_DATA:        /* p: dy1, dy2 | NULL, wq, dx;  i: cout1, cout2, lddy, ldw, lddx, B, H, W, Cin, accumulate */
             return yh_conv_pw_bwd_data((const float *)p[0], i[0], (const float *)p[1], i[1], i[2], (const float *)p[2], i[3],
                                        (float *)p[3], i[4], (int64_t)i[5] * i[6] * i[7], i[8], i[9], st);
         case YH_OP_NOP:
             return 0;
         case YH_OP_CONV_NARROW:
+            if (p[10])
+                return yh_conv_narrow_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (const float *)p[2],
+                                          (float *)p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], st);
             return yh_conv_narrow((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (float *)p[3], i[2],
                                   (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], st);
         case YH_OP_CONV_NARROW_DGRAD_S2:    /* same argument slots as YH_OP_CONV_BWD_DATA */
             return yh_conv_narrow_dgrad_s2((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], i[2], i[3], i[4], i[5],
                                            i[6], i[7], i[10], st);
         case YH_OP_CONV_NARROW_BWD_WEIGHT:  /* same argument slots as YH_OP_CONV_BWD_WEIGHT (k = 3 implied) */
-            return yh_conv_narrow_bwd_weight((const float *)p[0], i[0], (const float *)p[1], i[1], (float *)p[2], (float *)p[4], (float *)p[3],
-                                             o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[9], st);
+            return yh_conv_narrow_bwd_weight_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (float *)p[2],
+                                                 (float *)p[4], (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], i[6], i[7], i[9], st);
         case YH_OP_BF16_CONV_NARROW:
             return yh_bf16_conv_narrow(p[0], i[0], p[1], i[1], i[11], (const float *)p[2], p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6],
                                        i[7], i[8], i[9], i[10], st);

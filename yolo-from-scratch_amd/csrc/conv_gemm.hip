@@ -23,6 +23,8 @@ constexpr int BK = 32;
 constexpr int LDA = BK + 4;
 
 struct GatherGemm {
+    const float *icoef;   // input prologue table of `in` ([scale | shift | gate] rows, icoef_ld apart; yh_prologue) or null: forward only,
+    int icoef_ld;         // 16-byte staging (VEC == 4), single-source K
     const float *in, *w, *bias;
     const float *in2;     // optional second input (same geometry and ld): k >= ksplit reads in2 (pointwise K-concatenation)
     int ksplit;
@@ -137,11 +139,21 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
 
     // two register sets: chunk c+1 and chunk c+2 are both in flight while chunk c is multiplied
     f32x4 raA[AROWS], rbA[BPASS], raB[AROWS], rbB[BPASS];
-    auto load_tiles = [&](int c, f32x4 (&ra)[AROWS], f32x4 (&rb)[BPASS]) {
+    // input prologue: a chunk's coefficients (the thread's channel quad) are loaded with the chunk, the activation is applied when the
+    // chunk is parked in LDS; padding / rows past M stay zero: one validity bit per row and register set
+    const bool act = VEC == 4 && g.icoef != nullptr;       // workgroup-uniform
+    f32x4 pcA[3], pcB[3];
+    unsigned okA = 0, okB = 0;
+    auto load_tiles = [&](int c, f32x4 (&ra)[AROWS], f32x4 (&rb)[BPASS], f32x4 (&pc)[3], unsigned &okm) {
         const int k = c * BK + 4 * kq;
+        okm = 0;
         if (VEC == 4) {
             if (k < g.Ktot) {
                 int tap = (int)__umulhi((unsigned)k, g.cin_magic), ci = k - tap * g.Cin;
+                if (act) {
+                    pc[0] = *(const f32x4 *)(g.icoef + ci); pc[1] = *(const f32x4 *)(g.icoef + g.icoef_ld + ci);
+                    pc[2] = *(const f32x4 *)(g.icoef + 2 * g.icoef_ld + ci);
+                }
                 int dy = tapt[tap], dx = tapt[9 + tap];
                 int toff = (dy * g.Wi + dx) * g.ldi + ci;
                 const float *inb = (g.in2 && k >= g.ksplit) ? g.in2 - g.ksplit : g.in;   // two-source K (pointwise only)
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
                 for (int i = 0; i < AROWS; ++i) {
                     bool ok = (unsigned)(riy[i] + dy) < (unsigned)g.Hi && (unsigned)(rix[i] + dx) < (unsigned)g.Wi;
                     ra[i] = ok ? *(const f32x4 *)(inb + (roff[i] + toff)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    okm |= (unsigned)ok << i;
                 }
             } else {
 #pragma unroll
@@ -185,11 +198,18 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
             }
         }
     };
-    auto store_tiles = [&](int buf, f32x4 (&ra)[AROWS], f32x4 (&rb)[BPASS]) {
+    auto store_tiles = [&](int buf, f32x4 (&ra)[AROWS], f32x4 (&rb)[BPASS], const f32x4 (&pc)[3], unsigned okm) {
         float *a = As + buf * BM * LDA;
         float *b = Bs + buf * BK * BN;
 #pragma unroll
-        for (int i = 0; i < AROWS; ++i) *(f32x4 *)(a + ((t >> 3) + 32 * i) * LDA + 4 * kq) = ra[i];
+        for (int i = 0; i < AROWS; ++i) {
+            f32x4 v = ra[i];
+            if (act && (okm >> i & 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = yh_prologue(v[e], pc[0][e], pc[1][e], pc[2][e]);
+            }
+            *(f32x4 *)(a + ((t >> 3) + 32 * i) * LDA + 4 * kq) = v;
+        }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p)
             if (t / BQ + p * BROWS < BK) *(f32x4 *)(b + (t / BQ + p * BROWS) * BN + 4 * (t % BQ)) = rb[p];
@@ -232,19 +252,19 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmSet gs
     };
     // software pipeline, prefetch distance 2: at step c the loads of chunk c+2 are issued, chunk c is
     // multiplied from LDS, then chunk c+1 (loaded one step earlier) is written to the other LDS buffer.
-    load_tiles(cbeg, raA, rbA);
-    store_tiles(0, raA, rbA);
-    if (nchunks > 1) load_tiles(cbeg + 1, raB, rbB);
+    load_tiles(cbeg, raA, rbA, pcA, okA);
+    store_tiles(0, raA, rbA, pcA, okA);
+    if (nchunks > 1) load_tiles(cbeg + 1, raB, rbB, pcB, okB);
     __syncthreads();
     for (int c = 0; c < nchunks; c += 2) {
-        if (c + 2 < nchunks) load_tiles(cbeg + c + 2, raA, rbA);
+        if (c + 2 < nchunks) load_tiles(cbeg + c + 2, raA, rbA, pcA, okA);
         compute(0, g.Ktot - (cbeg + c) * BK);
-        if (c + 1 < nchunks) store_tiles(1, raB, rbB);
+        if (c + 1 < nchunks) store_tiles(1, raB, rbB, pcB, okB);
         __syncthreads();
         if (c + 1 >= nchunks) break;
-        if (c + 3 < nchunks) load_tiles(cbeg + c + 3, raB, rbB);
+        if (c + 3 < nchunks) load_tiles(cbeg + c + 3, raB, rbB, pcB, okB);
         compute(1, g.Ktot - (cbeg + c + 1) * BK);
-        if (c + 2 < nchunks) store_tiles(0, raA, rbA);
+        if (c + 2 < nchunks) store_tiles(0, raA, rbA, pcA, okA);
         __syncthreads();
     }
 
@@ -561,15 +581,25 @@ extern "C" int yh_conv_fwd_blocks(int B, int Hi, int Wi, int Cout, int k, int s)
     return cdiv(M, stats_bm(M, Cout));
 }
 
+extern "C" int yh_conv_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wf, int ldwf, const float *bias, float *y,
+                               int ldy, float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
 extern "C" int yh_conv_fwd(const float *x, int ldx, const float *wf, int ldwf, const float *bias, float *y, int ldy,
                            float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s,
                            void *stream) {
+    return yh_conv_fwd_act(x, ldx, nullptr, 0, wf, ldwf, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, k, s, stream);
+}
+extern "C" int yh_conv_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wf, int ldwf, const float *bias, float *y,
+                               int ldy, float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream) {
     YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_fwd: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(!icoef || ((((uintptr_t)icoef) & 15) == 0 && icoef_ld % 4 == 0 && icoef_ld >= Cin && Cin % 4 == 0 && ldx % 4 == 0 &&
+                          (((uintptr_t)x) & 15) == 0),
+               "conv_fwd: the input prologue needs 16-byte addressable input rows and table");
     YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_fwd: bad argument");
     YH_REQUIRE(ldx >= Cin && ldy >= Cout, "conv_fwd: ld smaller than channel count");
     YH_REQUIRE((int64_t)B * Hi * Wi * (int64_t)ldx < (1ll << 31), "conv_fwd: input too large for 32-bit pixel index");
     GatherGemm g{};
     const int p = k / 2;
+    g.icoef = icoef; g.icoef_ld = icoef_ld;
     g.in = x; g.w = wf; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.Hi = Hi; g.Wi = Wi; g.ldi = ldx; g.Cin = Cin; g.ldw = ldwf;
     g.Ho_f = (Hi + 2 * p - k) / s + 1; g.Wo_f = (Wi + 2 * p - k) / s + 1; g.ldo = ldy; g.N = Cout;

@@ -66,6 +66,8 @@ template <> struct NarrowIO<nbf16> {
 };
 
 struct Narrow {
+    const float *icoef;             // input prologue table [scale | shift | gate] of the x operand (see yh_prologue), or null
+    int icoef_ld;
     const void *in, *w;             // w: [tap][CIN][ldw] (forward pack) or [tap][COUT_of_conv = K][ldw] (backward pack); bf16: see NarrowIO
     const float *bias;
     void *out;
@@ -77,7 +79,7 @@ struct Narrow {
     int flip, accumulate;
 };
 
-template <int CIN, int COUT, int S, typename T>
+template <int CIN, int COUT, int S, typename T, bool ACT = false>
 __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
     typedef NarrowIO<T> IO;
     const T *const gin = (const T *)g.in;
@@ -129,6 +131,14 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         mx[k] = i < NPC ? (unsigned)(((q * IH + py) * ROWSZ + sx) * 4) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
     }
     typename IO::raw4 rx[NX];
+    // input prologue (ACT): the producer's BatchNorm + SiLU applied when a piece is parked.  Every piece of a thread covers the same
+    // channel quad (256 % Q == 0); padding stays zero AFTER the activation: one validity bit per piece, set by fetch
+    f32x4 psc, psh, pgt;
+    unsigned rok = 0;
+    if constexpr (ACT) {
+        const int ch = 4 * (t % Q);
+        psc = *(const f32x4 *)(g.icoef + ch); psh = *(const f32x4 *)(g.icoef + g.icoef_ld + ch); pgt = *(const f32x4 *)(g.icoef + 2 * g.icoef_ld + ch);
+    }
     // patch index (tx, ty, b) of pid, advanced by the grid size without divisions
     struct PIdx { int tx, ty, b; };
     const int gsx = (int)gridDim.x % g.tiles_x, gsr = (int)gridDim.x / g.tiles_x, gsy = gsr % g.tiles_y, gsb = gsr / g.tiles_y;
@@ -144,11 +154,15 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         const int tx = pi.tx, ty = pi.ty, b = pi.b;
         const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
         const T *xb = gin + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldi;
+        rok = 0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
             typename IO::raw4 v = IO::zero4();
-            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = IO::load4raw(xb + gx[k]);
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) {
+                v = IO::load4raw(xb + gx[k]);
+                if constexpr (ACT) rok |= 1u << k;
+            }
             rx[k] = v;
         }
     };
@@ -181,7 +195,16 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const Narrow g) {
         __syncthreads();                                  // the previous patch's fragments are consumed
 #pragma unroll
         for (int k = 0; k < NX; ++k)
-            if (t + 256 * k < NPC) *(f32x4 *)(xs + (mx[k] & 0xffffu)) = IO::widen(rx[k]);
+            if (t + 256 * k < NPC) {
+                f32x4 v = IO::widen(rx[k]);
+                if constexpr (ACT) {
+                    if (rok >> k & 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = yh_prologue(v[e], psc[e], psh[e], pgt[e]);
+                    }
+                }
+                *(f32x4 *)(xs + (mx[k] & 0xffffu)) = v;
+            }
         __syncthreads();
         advance(nxt);
         if (pid + (int)gridDim.x < npatch) fetch(nxt);
@@ -796,6 +819,8 @@ __global__ __launch_bounds__(256) void narrow_dgrad_s2_bf16_kernel(const Narrow 
 // flight under the MFMAs of the current one), keeps the 9 (x COUT/16) accumulator tiles in registers the whole time and
 // writes one raw slab at the end; a fixed-order reduction turns the slabs into OIHW.  Every x and dY element is read once.
 struct NarrowW {
+    const float *icoef;           // input prologue table of x, or null
+    int icoef_ld;
     const void *x, *dy;
     float *ws;
     float *bws;                   // != NULL: per-workgroup column sums of dY (the conv's bias gradient), [grid][COUT]
@@ -817,7 +842,7 @@ template <int CIN, int COUT, int S> struct NarrowWCfg {
     static constexpr int SLAB = RG * NB * 256;
 };
 
-template <int CIN, int COUT, int S, typename T>
+template <int CIN, int COUT, int S, typename T, bool ACT = false>
 __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
     typedef NarrowWCfg<CIN, COUT, S> C;
     typedef NarrowIO<T> IO;
@@ -854,6 +879,12 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
         md[k] = i < C::DPIECES ? (unsigned)(((q >> 2) * TH * TW + p) * 16 + 4 * (q & 3)) | (unsigned)py << 16 | (unsigned)px << 24 : 255u << 16;
     }
     typename IO::raw4 rx[NX], rd[ND];
+    f32x4 psc, psh, pgt;                                                // input prologue, as in narrow_conv_kernel
+    unsigned rok = 0;
+    if constexpr (ACT) {
+        const int ch = 4 * (t % QX);
+        psc = *(const f32x4 *)(g.icoef + ch); psh = *(const f32x4 *)(g.icoef + g.icoef_ld + ch); pgt = *(const f32x4 *)(g.icoef + 2 * g.icoef_ld + ch);
+    }
     auto fetch = [&](int pid) {
         const int tx = pid % g.tiles_x;
         const int rest = pid / g.tiles_x;
@@ -862,11 +893,15 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
         const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
         const T *xb = (const T *)g.x + ((ptrdiff_t)(b * g.Hi + iy0) * g.Wi + ix0) * g.ldx;
         const T *db = (const T *)g.dy + ((ptrdiff_t)(b * g.Ho + oy0) * g.Wo + ox0) * g.lddy;
+        rok = 0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int iy = iy0 + (int)((mx[k] >> 16) & 255u), ix = ix0 + (int)(mx[k] >> 24);
             typename IO::raw4 v = IO::zero4();
-            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) v = IO::load4raw(xb + gx[k]);
+            if ((unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) {
+                v = IO::load4raw(xb + gx[k]);
+                if constexpr (ACT) rok |= 1u << k;
+            }
             rx[k] = v;
         }
 #pragma unroll
@@ -880,7 +915,16 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowW g) {
     auto park = [&]() {
 #pragma unroll
         for (int k = 0; k < NX; ++k)
-            if (t + 256 * k < C::XPIECES) *(f32x4 *)(xs + (mx[k] & 0xffffu)) = IO::widen(rx[k]);
+            if (t + 256 * k < C::XPIECES) {
+                f32x4 v = IO::widen(rx[k]);
+                if constexpr (ACT) {
+                    if (rok >> k & 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = yh_prologue(v[e], psc[e], psh[e], pgt[e]);
+                    }
+                }
+                *(f32x4 *)(xs + (mx[k] & 0xffffu)) = v;
+            }
 #pragma unroll
         for (int k = 0; k < ND; ++k)
             if (t + 256 * k < C::DPIECES) *(f32x4 *)(ds + (md[k] & 0xffffu)) = IO::widen(rd[k]);
@@ -1016,13 +1060,17 @@ int narrow_wgrad_grid(int npatch, int Cin) {
 
 template <int CIN, int COUT, int S, typename T>
 int narrow_wgrad_launch(NarrowW g, float *dw, float *dbias, int cin_real, hipStream_t st) {
+    static_assert(NarrowWCfg<CIN, COUT, S>::NX <= 32 && (256 % (CIN / 4)) == 0, "piece validity mask / per-thread channel quad");
     typedef NarrowWCfg<CIN, COUT, S> C;
     g.tiles_x = cdiv(g.Wo, C::TW);
     g.tiles_y = cdiv(g.Ho, C::TH);
     g.npatch = g.B * g.tiles_x * g.tiles_y;
     const int grid = narrow_wgrad_grid(g.npatch, CIN);
     g.bws = dbias ? g.ws + (size_t)grid * C::SLAB : nullptr;
-    hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S, T>), dim3(grid), dim3(256), 0, st, g);
+    if (g.icoef) {
+        if constexpr (CIN == 16) hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S, T, true>), dim3(grid), dim3(256), 0, st, g);
+        else YH_REQUIRE(false, "conv_narrow_bwd_weight: no input prologue for the first layer");
+    } else hipLaunchKernelGGL((narrow_wgrad_kernel<CIN, COUT, S, T>), dim3(grid), dim3(256), 0, st, g);
     YH_CHECK_LAUNCH("conv_narrow_bwd_weight");
     hipLaunchKernelGGL((narrow_wgrad_reduce_kernel<CIN, COUT>), dim3(cdiv(COUT * cin_real * 9 + (dbias ? COUT : 0), 16)), dim3(256), 0, st,
                        g.ws, dw, grid, cin_real, g.bws, dbias);
@@ -1094,22 +1142,27 @@ extern "C" int yh_bf16_conv_narrow_dgrad_s2(const void *dy, int lddy, const void
 }
 
 template <typename T>
-static int narrow_conv_t(const T *x, int ldx, const T *w, int ldw, int kpad, const float *bias, T *y, int ldy, float *bn_partials, int B,
-                         int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream) {
+static int narrow_conv_t(const T *x, int ldx, const float *icoef, int icoef_ld, const T *w, int ldw, int kpad, const float *bias, T *y, int ldy,
+                         float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate, void *stream) {
     YH_REQUIRE(x && w && y && B > 0 && Hi > 0 && Wi > 0, "conv_narrow: bad argument");
+    YH_REQUIRE(!icoef || (Cin == 16 && !flip_taps && ((uintptr_t)icoef & 15) == 0 && icoef_ld % 4 == 0 && icoef_ld >= Cin),
+               "conv_narrow: the input prologue needs a 16-channel forward layer and a 16-byte aligned table");
     YH_REQUIRE(yh_conv_narrow_ok(Cin, Cout, 3, s), "conv_narrow: unsupported shape %d -> %d stride %d", Cin, Cout, s);
     YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & (4 * sizeof(T) - 1)) == 0 && ldy >= Cout && ldw >= Cout,
                "conv_narrow: views must be addressable in 4-channel pieces");
     YH_REQUIRE(!(flip_taps && s != 1), "conv_narrow: flipped taps (backward-data) only for stride 1");
     Narrow g{};
-    g.in = x; g.w = w; g.bias = bias; g.out = y; g.stats = bn_partials; g.kpad = kpad;
+    g.in = x; g.w = w; g.bias = bias; g.out = y; g.stats = bn_partials; g.kpad = kpad; g.icoef = icoef; g.icoef_ld = icoef_ld;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.B = B; g.Hi = Hi; g.Wi = Wi;
     g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
     g.flip = flip_taps ? 1 : 0; g.accumulate = accumulate ? 1 : 0;
     const int nt = narrow_tiles(g.Ho, g.Wo, Cin, s, g.tiles_x, g.tiles_y);
     hipStream_t st = (hipStream_t)stream;
     const int grid = narrow_conv_grid(B * nt);
-    if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1, T>), dim3(grid), dim3(256), 0, st, g);
+    if (icoef) {
+        if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1, T, true>), dim3(grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((narrow_conv_kernel<16, 32, 2, T, true>), dim3(grid), dim3(256), 0, st, g);
+    } else if (s == 1) hipLaunchKernelGGL((narrow_conv_kernel<16, 16, 1, T>), dim3(grid), dim3(256), 0, st, g);
     else if (Cin == 4) {
         bool fast = false;
         if constexpr (std::is_same<T, nbf16>::value)      // the bf16-MFMA form reads pixels and filter octets in 8-byte pieces
@@ -1133,14 +1186,18 @@ static int narrow_conv_t(const T *x, int ldx, const T *w, int ldw, int kpad, con
 extern "C" int yh_conv_narrow(const float *x, int ldx, const float *w, int ldw, const float *bias, float *y, int ldy,
                               float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate,
                               void *stream) {
-    return narrow_conv_t<float>(x, ldx, w, ldw, 0, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, s, flip_taps, accumulate, stream);
+    return narrow_conv_t<float>(x, ldx, nullptr, 0, w, ldw, 0, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, s, flip_taps, accumulate, stream);
+}
+extern "C" int yh_conv_narrow_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *w, int ldw, const float *bias,
+                                  float *y, int ldy, float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, void *stream) {
+    return narrow_conv_t<float>(x, ldx, icoef, icoef_ld, w, ldw, 0, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, s, 0, 0, stream);
 }
 extern "C" int yh_bf16_conv_narrow(const void *x, int ldx, const void *w, int ldw, int kpad, const float *bias, void *y, int ldy,
                                    float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int s, int flip_taps, int accumulate,
                                    void *stream) {
     YH_REQUIRE(kpad >= Cin && kpad % 8 == 0, "bf16_conv_narrow: bad pack padding");
-    return narrow_conv_t<nbf16>((const nbf16 *)x, ldx, (const nbf16 *)w, ldw, kpad, bias, (nbf16 *)y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, s,
-                                flip_taps, accumulate, stream);
+    return narrow_conv_t<nbf16>((const nbf16 *)x, ldx, nullptr, 0, (const nbf16 *)w, ldw, kpad, bias, (nbf16 *)y, ldy, bn_partials, B, Hi, Wi, Cin,
+                                Cout, s, flip_taps, accumulate, stream);
 }
 
 extern "C" int yh_conv_narrow_bwd_weight_ok(int Cin, int cin_real, int Cout, int k, int s) {
@@ -1160,9 +1217,11 @@ extern "C" int64_t yh_conv_narrow_bwd_weight_ws(int B, int Hi, int Wi, int Cin, 
 }
 
 template <typename T>
-static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float *dw, float *dbias, float *ws, int64_t ws_floats, int B, int Hi,
-                               int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
+static int narrow_bwd_weight_t(const T *x, int ldx, const float *icoef, int icoef_ld, const T *dy, int lddy, float *dw, float *dbias, float *ws,
+                               int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
     YH_REQUIRE(x && dy && dw && ws && B > 0 && Hi > 0 && Wi > 0, "conv_narrow_bwd_weight: bad argument");
+    YH_REQUIRE(!icoef || (Cin == 16 && ((uintptr_t)icoef & 15) == 0 && icoef_ld % 4 == 0 && icoef_ld >= Cin),
+               "conv_narrow_bwd_weight: the input prologue needs a 16-channel layer and a 16-byte aligned table");
     YH_REQUIRE(yh_conv_narrow_bwd_weight_ok(Cin, cin_real, Cout, 3, s), "conv_narrow_bwd_weight: unsupported shape %d(%d) -> %d stride %d",
                Cin, cin_real, Cout, s);
     YH_REQUIRE(ldx >= Cin && ldx % 4 == 0 && ((uintptr_t)x & (4 * sizeof(T) - 1)) == 0 && lddy >= Cout && lddy % 4 == 0 &&
@@ -1170,7 +1229,7 @@ static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float
                "conv_narrow_bwd_weight: views must be addressable in 4-channel pieces");
     YH_REQUIRE(ws_floats >= yh_conv_narrow_bwd_weight_ws(B, Hi, Wi, Cin, Cout, s), "conv_narrow_bwd_weight: workspace too small");
     NarrowW g{};
-    g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy; g.B = B; g.Hi = Hi; g.Wi = Wi;
+    g.x = x; g.dy = dy; g.ws = ws; g.ldx = ldx; g.lddy = lddy; g.B = B; g.Hi = Hi; g.Wi = Wi; g.icoef = icoef; g.icoef_ld = icoef_ld;
     g.Ho = (Hi - 1) / s + 1; g.Wo = (Wi - 1) / s + 1;
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 16 && s == 1) return narrow_wgrad_launch<16, 16, 1, T>(g, dw, dbias, cin_real, st);
@@ -1179,11 +1238,16 @@ static int narrow_bwd_weight_t(const T *x, int ldx, const T *dy, int lddy, float
 }
 extern "C" int yh_conv_narrow_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *dbias, float *ws,
                                          int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s, void *stream) {
-    return narrow_bwd_weight_t<float>(x, ldx, dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s, stream);
+    return narrow_bwd_weight_t<float>(x, ldx, nullptr, 0, dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s, stream);
+}
+extern "C" int yh_conv_narrow_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw,
+                                             float *dbias, float *ws, int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout,
+                                             int s, void *stream) {
+    return narrow_bwd_weight_t<float>(x, ldx, icoef, icoef_ld, dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, s, stream);
 }
 extern "C" int yh_bf16_conv_narrow_bwd_weight(const void *x, int ldx, const void *dy, int lddy, float *dw, float *dbias, float *ws,
                                               int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int s,
                                               void *stream) {
-    return narrow_bwd_weight_t<nbf16>((const nbf16 *)x, ldx, (const nbf16 *)dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout,
-                                      s, stream);
+    return narrow_bwd_weight_t<nbf16>((const nbf16 *)x, ldx, nullptr, 0, (const nbf16 *)dy, lddy, dw, dbias, ws, ws_floats, B, Hi, Wi, Cin, cin_real,
+                                      Cout, s, stream);
 }

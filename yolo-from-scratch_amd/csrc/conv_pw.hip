@@ -40,6 +40,8 @@ __device__ __forceinline__ float vget(const typename Vec<V>::type &v, int e) {
 
 struct PwW {
     const float *x, *dy;
+    const float *icoef;         // input prologue table of x ([scale | shift | gate] rows, icoef_ld apart; yh_prologue), or null
+    int icoef_ld;
     float *ws;
     int ldx, lddy, Cin, Cout;
     int M, pps;                 // pixels, pixels per split (multiple of 64)
@@ -67,6 +69,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwW g) {
     const unsigned ldx4 = (unsigned)g.ldx * 4u, ldd4 = (unsigned)g.lddy * 4u;
     int p = p_begin + lh;                      // this lane's pixel of the next k-step
 
+    // input prologue: a lane's XV channels are the same for every pixel -- coefficients loaded once.  Pixels past the range load
+    // zeros on BOTH operands, so whatever the prologue makes of an x zero meets a dY zero.
+    const bool act = g.icoef != nullptr;                   // workgroup-uniform
+    float psc[XV], psh[XV], pgt[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        int ch = ci0 + XV * lr + i;
+        ch = ch < g.Cin ? ch : g.Cin - 1;
+        psc[i] = act ? g.icoef[ch] : 1.f; psh[i] = act ? g.icoef[g.icoef_ld + ch] : 0.f; pgt[i] = act ? g.icoef[2 * g.icoef_ld + ch] : 0.f;
+    }
     xv_t XA[SPS], XB[SPS];
     dv_t DA[SPS], DB[SPS];
     auto load_stage = [&](xv_t (&X)[SPS], dv_t (&D)[SPS]) {
@@ -90,10 +102,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const PwW g) {
 #pragma unroll
         for (int q = 0; q < SPS; ++q)
 #pragma unroll
-            for (int i = 0; i < XV; ++i)
+            for (int i = 0; i < XV; ++i) {
+                float xv = vget<XV>(X[q], i);
+                if (act) xv = yh_prologue(xv, psc[i], psh[i], pgt[i]);
 #pragma unroll
                 for (int j = 0; j < DV; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget<XV>(X[q], i), vget<DV>(D[q], j), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, vget<DV>(D[q], j), acc[i][j], 0, 0, 0);
+            }
     };
 
     const int nstages = (g.pps / 4) / (2 * SPS);
@@ -196,10 +211,17 @@ extern "C" int64_t yh_conv_pw_bwd_weight_ws(int64_t M, int Cin, int Cout) {
     return need;
 }
 
+extern "C" int yh_conv_pw_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw,
+                                         float *ws, int64_t ws_floats, int64_t M, int Cin, int Cout, void *stream);
 extern "C" int yh_conv_pw_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
                                      int64_t M, int Cin, int Cout, void *stream) {
-    YH_REQUIRE(x && dy && dw && ws && ldx >= Cin && lddy >= Cout, "conv_pw_bwd_weight: bad argument");
+    return yh_conv_pw_bwd_weight_act(x, ldx, nullptr, 0, dy, lddy, dw, ws, ws_floats, M, Cin, Cout, stream);
+}
+extern "C" int yh_conv_pw_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw,
+                                         float *ws, int64_t ws_floats, int64_t M, int Cin, int Cout, void *stream) {
+    YH_REQUIRE(x && dy && dw && ws && ldx >= Cin && lddy >= Cout && (!icoef || icoef_ld >= Cin), "conv_pw_bwd_weight: bad argument");
     PwW g{};
+    g.icoef = icoef; g.icoef_ld = icoef_ld;
     int nsplit, XV, DV;
     int rc = pw_plan(g, nsplit, XV, DV, M, Cin, Cout, vec_width(x, ldx), vec_width(dy, lddy));
     if (rc) return rc;
@@ -250,6 +272,8 @@ struct PwG {
     unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps (tools/pw_probe.py)
 #endif
     int ldr, act, up2, H, W;    // H, W: image size (up2 needs the pixel's row / column)
+    const float *icoef;         // input prologue table of `in` ([scale | shift | gate] rows, icoef_ld apart; yh_prologue), or null:
+    int icoef_ld;               // tiled and streaming kernels, single-source K only
 };
 
 template <int TM, int NT>
@@ -384,7 +408,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const PwG g) {
 // lane's four consecutive k); wave (wm, wn) multiplies TMW x 32 rows by ITS OWN 32 columns, so each weight fragment is
 // fetched by exactly one wave of the workgroup.  Same operand maps, k order per 8-channel group, epilogue and partial-sum
 // contract as pw_gemm_kernel.
-template <int TMW, int WN>
+template <int TMW, int WN, bool ACT = false>
 __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
     constexpr int WM = 4 / WN, BM = 32 * TMW * WM, KC = 128, LDA = KC + 4, NP = BM * (KC / 4) / 256;
     extern __shared__ __attribute__((aligned(16))) float pw_as[];     // [BM][LDA]; reused for the partial-sum exchange
@@ -420,7 +444,25 @@ __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
     auto fetch = [&](int tile, int ci) {
         fetch_q(tile, ci, 0); fetch_q(tile, ci, 1); fetch_q(tile, ci, 2); fetch_q(tile, ci, 3);
     };
-    auto park = [&]() {
+    // input prologue: the chunk's coefficients for this thread's channel quad come from the table when the chunk is parked (three
+    // 16-byte L1 / L2 hits per 128-channel chunk).  Rows past M and channels past K are parked as whatever the prologue makes of
+    // their zeros: those rows are never stored or summed, those channels never multiplied (ns = kc >> 3 groups).
+    auto park = [&](int kb) {
+        if constexpr (ACT) {
+            const float *cp = g.icoef + kb + 4 * col4;
+            const bool live = kb + 4 * col4 < g.K1;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc = live ? *(const f32x4 *)cp : z4, sh = live ? *(const f32x4 *)(cp + g.icoef_ld) : z4,
+                        gt = live ? *(const f32x4 *)(cp + 2 * g.icoef_ld) : z4;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                f32x4 v = rx[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = yh_prologue(v[e], sc[e], sh[e], gt[e]);
+                *(f32x4 *)(pw_as + (row0 + 8 * j) * LDA + 4 * col4) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NP; ++j) *(f32x4 *)(pw_as + (row0 + 8 * j) * LDA + 4 * col4) = rx[j];
     };
@@ -475,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
             int kc = (seg2 ? g.K - g.K1 : g.K1) - kb;
             if (kc > KC) kc = KC;
             __syncthreads();                                                // the previous chunk's fragments / sums are consumed
-            park();
+            park(kb);
             __syncthreads();
 #ifdef YH_PW_STAMPS
             if (ci == 0) st1 = __builtin_amdgcn_s_memtime();
@@ -604,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void pw_tile_kernel(const PwG g) {
 template <int NT, int KC>
 __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
     __shared__ float red[4][32 * NT][2];
+    __shared__ __attribute__((aligned(16))) float ctab[3][8 * KC];      // input prologue table of the layer's K = 8 KC channels
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g.in, 0, g.in_bytes, 0x00020000);
@@ -705,17 +748,37 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
                 }
             }
     };
+    // input prologue (the layers this kernel runs are HBM-bound: the sigmoid work of one wave hides under the loads of the others).
+    // Pixels past M load zeros and come out as whatever the prologue makes of them: their rows are never stored or summed.
+    const bool act = g.icoef != nullptr;                   // workgroup-uniform
+    if (act) {
+        for (int i = t; i < 3 * 8 * KC; i += 256) ctab[i / (8 * KC)][i % (8 * KC)] = g.icoef[(i / (8 * KC)) * g.icoef_ld + i % (8 * KC)];
+        __syncthreads();
+    }
+    auto prologue = [&](f32x4 (&a)[KC]) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const f32x4 sc = *(const f32x4 *)&ctab[0][8 * c + 4 * lh], sh = *(const f32x4 *)&ctab[1][8 * c + 4 * lh],
+                        gt = *(const f32x4 *)&ctab[2][8 * c + 4 * lh];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[c][e] = yh_prologue(a[c][e], sc[e], sh[e], gt[e]);
+        }
+    };
     f32x4 aA[KC], aB[KC];
     int grp = blockIdx.x * 4 + wave;
     load(grp, aA);
     for (; grp < ngroups; grp += 2 * stride) {
         load(grp + stride, aB);
         __builtin_amdgcn_sched_barrier(0);
+        if (act) prologue(aA);
         compute(grp, aA);
         __builtin_amdgcn_sched_barrier(0);
         load(grp + 2 * stride, aA);
         __builtin_amdgcn_sched_barrier(0);
-        if (grp + stride < ngroups) compute(grp + stride, aB);
+        if (grp + stride < ngroups) {
+            if (act) prologue(aB);
+            compute(grp + stride, aB);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     if (g.stats) {
@@ -803,6 +866,9 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
     g.in2_bytes = (unsigned)(((int64_t)(g.M - 1) * g.ldi + (g.K - g.K1)) * 4);
     const int NT = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
     const bool fused = g.act || g.up2 || g.res;          // the streaming form has no inference epilogue
+    YH_REQUIRE(!g.icoef || (!fused && !g.in2 && (((uintptr_t)g.icoef) & 15) == 0 && g.icoef_ld % 4 == 0 && g.icoef_ld >= g.K &&
+                            (pw_use_stream(g.M, g.K, g.N) || (g.K % 32 == 0 && pw_use_tile(g.K, g.N)))),
+               "conv_pw: the input prologue runs on the streaming and the tiled forward kernels only (yh_conv_pw_prologue_ok)");
     if (!fused && pw_use_stream(g.M, g.K, g.N)) {
         dim3 sg(pw_stream_blocks(g.M));
         const int KC = g.K / 8;
@@ -829,10 +895,15 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
 #endif
         const size_t smem = (size_t)BM * 132 * sizeof(float);
         int rc = 0;
-#define YH_PWT(tmw, wn)                                                                          \
-    do {                                                                                         \
-        rc = yh_ensure_dyn_smem((const void *)pw_tile_kernel<tmw, wn>, smem);                    \
-        if (!rc) hipLaunchKernelGGL((pw_tile_kernel<tmw, wn>), tg, dim3(256), smem, st, g);      \
+#define YH_PWT(tmw, wn)                                                                                  \
+    do {                                                                                                 \
+        if (g.icoef) {                                                                                   \
+            rc = yh_ensure_dyn_smem((const void *)pw_tile_kernel<tmw, wn, true>, smem);                  \
+            if (!rc) hipLaunchKernelGGL((pw_tile_kernel<tmw, wn, true>), tg, dim3(256), smem, st, g);    \
+        } else {                                                                                         \
+            rc = yh_ensure_dyn_smem((const void *)pw_tile_kernel<tmw, wn>, smem);                        \
+            if (!rc) hipLaunchKernelGGL((pw_tile_kernel<tmw, wn>), tg, dim3(256), smem, st, g);          \
+        }                                                                                                \
     } while (0)
         if (WN == 4) { if (BM == 64) YH_PWT(2, 4); else YH_PWT(4, 4); }
         else if (WN == 2) { if (BM == 64) YH_PWT(1, 2); else YH_PWT(2, 2); }
@@ -887,10 +958,20 @@ extern "C" int yh_pw_pack_multi(const void *table, int n, void *stream) {
     return 0;
 }
 
+extern "C" int yh_conv_pw_prologue_ok(int64_t M, int Cin, int Cout) {
+    return (pw_use_stream(M, Cin, Cout) || (Cin % 32 == 0 && pw_use_tile(Cin, Cout))) ? 1 : 0;
+}
+extern "C" int yh_conv_pw_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias,
+                                  float *y, int ldy, float *bn_partials, int64_t M, int Cin, int Cout, void *stream);
 extern "C" int yh_conv_pw_fwd(const float *x, int ldx, const float *wq, int ldw, const float *bias, float *y, int ldy,
                               float *bn_partials, int64_t M, int Cin, int Cout, void *stream) {
+    return yh_conv_pw_fwd_act(x, ldx, nullptr, 0, wq, ldw, bias, y, ldy, bn_partials, M, Cin, Cout, stream);
+}
+extern "C" int yh_conv_pw_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias,
+                                  float *y, int ldy, float *bn_partials, int64_t M, int Cin, int Cout, void *stream) {
     YH_REQUIRE(x && wq && y && M > 0 && M < (1ll << 30) && ldx >= Cin && ldy >= Cout, "conv_pw_fwd: bad argument");
     PwG g{};
+    g.icoef = icoef; g.icoef_ld = icoef_ld;
     g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
     return launch_pw_gemm(g, (hipStream_t)stream);
@@ -907,12 +988,22 @@ extern "C" int yh_conv_pw_fwd_fused(const float *x, int ldx, const float *wq, in
     return launch_pw_gemm(g, (hipStream_t)stream);
 }
 
+extern "C" int yh_conv_pw_fwd2_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias1,
+                                   float *y1, int ldy1, float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2,
+                                   float *bn_partials2, int cout2, int64_t M, int Cin, void *stream);
 extern "C" int yh_conv_pw_fwd2(const float *x, int ldx, const float *wq, int ldw, const float *bias1, float *y1, int ldy1,
                                float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2,
                                int cout2, int64_t M, int Cin, void *stream) {
+    return yh_conv_pw_fwd2_act(x, ldx, nullptr, 0, wq, ldw, bias1, y1, ldy1, bn_partials1, cout1, bias2, y2, ldy2, bn_partials2, cout2, M, Cin,
+                               stream);
+}
+extern "C" int yh_conv_pw_fwd2_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias1,
+                                   float *y1, int ldy1, float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2,
+                                   float *bn_partials2, int cout2, int64_t M, int Cin, void *stream) {
     YH_REQUIRE(x && wq && y1 && y2 && M > 0 && M < (1ll << 30) && ldx >= Cin && ldy1 >= cout1 && ldy2 >= cout2 && cout1 > 0 && cout2 > 0 &&
                    (!bn_partials1) == (!bn_partials2), "conv_pw_fwd2: bad argument");
     PwG g{};
+    g.icoef = icoef; g.icoef_ld = icoef_ld;
     g.in = x; g.Wq = wq; g.bias = bias1; g.bias2 = bias2; g.out = y1; g.out2 = y2; g.stats = bn_partials1; g.stats2 = bn_partials2;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy1; g.ldo2 = ldy2; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = cout1 + cout2; g.N1 = cout1;
     return launch_pw_gemm(g, (hipStream_t)stream);

@@ -22,6 +22,8 @@ constexpr int PMAX = 40;   // output pixels per segment (even, chosen per layer 
 
 struct Wgrad {
     const float *x, *dy;
+    const float *icoef;         // input prologue table of x ([scale | shift | gate] rows, icoef_ld apart; yh_prologue), or null
+    int icoef_ld;
     float *ws;
     int ldx, lddy;
     int B, Hi, Wi, Ho, Wo;
@@ -111,18 +113,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
     if (seg_end > g.nseg_total) seg_end = g.nseg_total;
 
     f32x4 rx[XL], rd[DL];
+    // input prologue: applied when a segment is parked.  The channel quad of a thread's slots is xc[j] (the same for every slot when
+    // 256 % (CIT / 4) == 0, which the launcher requires with a table); padding must stay zero AFTER the activation: validity bits.
+    const bool act = g.icoef != nullptr;                   // workgroup-uniform
+    f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f}, pgt = {0.f, 0.f, 0.f, 0.f};
+    unsigned xokm = 0;
+    if (act) {
+        int ch = ci0 + xc[0];
+        ch = ch + 4 <= g.Cin ? ch : 0;
+        psc = *(const f32x4 *)(g.icoef + ch); psh = *(const f32x4 *)(g.icoef + g.icoef_ld + ch); pgt = *(const f32x4 *)(g.icoef + 2 * g.icoef_ld + ch);
+    }
     auto load_seg = [&](int seg) {
         const int sr = seg % g.nseg_row, rowid = seg / g.nseg_row;
         const int ho = rowid % g.Ho, b = rowid / g.Ho;
         const int w0 = sr * P;
         const int pv = (g.Wo - w0) < P ? (g.Wo - w0) : P;
         const int xcols = (pv - 1) * g.s + g.k;
+        xokm = 0;
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
             int hi = ho * g.s + xkh[j] - g.pad, wi = w0 * g.s - g.pad + xcol[j];
             int c = ci0 + xc[j];
             bool ok = xkh[j] >= 0 && xcol[j] < xcols && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi && c < g.Cin;
             rx[j] = ok ? *(const f32x4 *)(g.x + ((size_t)(b * g.Hi + hi) * g.Wi + wi) * g.ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xokm |= (unsigned)ok << j;
         }
         if (g.vec_dy) {
 #pragma unroll
@@ -137,7 +151,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const Wgrad g) {
     auto store_seg = [&](int seg) {
 #pragma unroll
         for (int j = 0; j < XL; ++j)
-            if (xkh[j] >= 0) *(f32x4 *)(Xs + (xkh[j] * XW + xcol[j]) * CIT + xc[j]) = rx[j];
+            if (xkh[j] >= 0) {
+                f32x4 v = rx[j];
+                if (act && (xokm >> j & 1)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = yh_prologue(v[e], psc[e], psh[e], pgt[e]);
+                }
+                *(f32x4 *)(Xs + (xkh[j] * XW + xcol[j]) * CIT + xc[j]) = v;
+            }
         if (g.vec_dy) {
 #pragma unroll
             for (int j = 0; j < DL; ++j)
@@ -344,10 +365,25 @@ extern "C" int64_t yh_conv_bwd_weight_ws(int B, int Hi, int Wi, int Cin, int Cou
     return (int64_t)pl.nsplit * k * k * Cin * Cout;
 }
 
+extern "C" int yh_conv_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                                      int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k, int s, void *stream);
 extern "C" int yh_conv_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws,
                                   int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k,
                                   int s, void *stream) {
+    return yh_conv_bwd_weight_act(x, ldx, nullptr, 0, dy, lddy, dw, ws, ws_floats, B, Hi, Wi, Cin, cin_real, Cout, k, s, stream);
+}
+extern "C" int yh_conv_bwd_weight_prologue_ok(int B, int Hi, int Wi, int Cin, int Cout, int k, int s) {
+    Plan pl;
+    if (make_plan(pl, B, Hi, Wi, Cin, Cout, k, s)) return 0;
+    const int citq = pl.g.CIT / 4;
+    return (citq > 0 && 256 % citq == 0 && pl.g.CIT % 4 == 0) ? 1 : 0;       // every staging slot of a thread covers the same channel quad
+}
+extern "C" int yh_conv_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                                      int64_t ws_floats, int B, int Hi, int Wi, int Cin, int cin_real, int Cout, int k, int s, void *stream) {
     YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2), "conv_bwd_weight: unsupported k=%d s=%d", k, s);
+    YH_REQUIRE(!icoef || ((((uintptr_t)icoef) & 15) == 0 && icoef_ld % 4 == 0 && icoef_ld >= Cin && cin_real == Cin &&
+                          yh_conv_bwd_weight_prologue_ok(B, Hi, Wi, Cin, Cout, k, s)),
+               "conv_bwd_weight: the input prologue needs a 16-byte aligned table and a slab whose channel tile divides the staging plan");
     YH_REQUIRE(x && dy && dw && ws && B > 0 && Cin > 0 && Cout > 0 && cin_real > 0 && cin_real <= Cin,
                "conv_bwd_weight: bad argument");
     YH_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0,
@@ -358,7 +394,7 @@ extern "C" int yh_conv_bwd_weight(const float *x, int ldx, const float *dy, int 
     if (rc) { yh_set_error("conv_bwd_weight: unsupported shape"); return rc; }
     int64_t need = (int64_t)pl.nsplit * k * k * Cin * Cout;
     if (ws_floats < need) { yh_set_error("conv_bwd_weight: workspace %lld < %lld floats", (long long)ws_floats, (long long)need); return YH_E_WORKSPACE; }
-    pl.g.x = x; pl.g.dy = dy; pl.g.ws = ws; pl.g.ldx = ldx; pl.g.lddy = lddy;
+    pl.g.x = x; pl.g.dy = dy; pl.g.ws = ws; pl.g.ldx = ldx; pl.g.lddy = lddy; pl.g.icoef = icoef; pl.g.icoef_ld = icoef_ld;
     pl.g.vec_dy = (lddy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (pl.g.COT % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     switch (pl.NT) {

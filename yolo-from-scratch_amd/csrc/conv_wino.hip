@@ -4,17 +4,15 @@
 //
 // With channels the element-wise product becomes 16 independent GEMMs (one per position (xi, nu) of the 4x4
 // transformed tile):  M[p][tile][n] = sum_k V[p][tile][k] * U[p][k][n]  -- 4/9 of the multiplies of the direct
-// form (2.25x fewer MFMA cycles).  Everything is fused in one kernel, and the main loop touches neither LDS nor a
-// barrier:
-//   * a workgroup owns 32 consecutive output tiles (linear over batch x tile rows x tile cols) x 32*NT channels;
-//     wave w owns transform row xi = w (positions 4w .. 4w+3);
-//   * lane (tile = lane & 31, q = lane >> 5) loads, per chunk of 8 input channels, the two input rows that
-//     row xi of B^T d needs (4 pixels x float4 of channels 4q..4q+3 each), applies the transform in registers and
-//     holds V[nu][tile][4q..4q+3] -- which is exactly the A operand this lane feeds to the MFMA (row = lane & 31,
-//     k-group = lane >> 5), so V never leaves the register file;
+// form (2.25x fewer MFMA cycles).  Everything is fused in one kernel (wino_lds_kernel):
+//   * a workgroup owns a 2-D block of 32 output tiles x 32*NT channels; wave w owns transform row xi = w (positions 4w .. 4w+3);
+//   * per chunk of 8 input channels the block's input patch is staged ONCE through LDS (rounds 1-3 loaded it straight into
+//     registers: every pixel was requested 3.4 times and the loop ran at the CU's cache-line rate, not at the MFMA rate);
+//   * lane (tile = lane & 31, q = lane >> 5) reads the two patch rows that row xi of B^T d needs (4 pixels x float4 of
+//     channels 4q..4q+3 each), applies the transform in registers and holds V[nu][tile][4q..4q+3] -- which is exactly the
+//     A operand this lane feeds to the MFMA (row = lane & 31, k-group = lane >> 5);
 //   * U is pre-transformed into a k-quad interleaved layout [16][K/4][N][4], so a B fragment (4 k values of one
-//     column) is one float4 load, coalesced over the 32 columns of a tile; it is private to the wave as well;
-//   * loads for chunk c+1 are issued before the 32*NT/2 MFMAs of chunk c;
+//     column) is one float4 load, coalesced over the 32 columns of a tile; it is private to the wave;
 //   * epilogue: the nu-contraction of A^T M A is lane-local (the four positions of a wave), the xi-contraction
 //     goes through LDS; then bias / accumulate / BatchNorm partial sums exactly as the direct kernel.
 // The same kernel computes backward-data (correlation of dY with the flipped, transposed filter).
@@ -52,15 +50,11 @@ struct Wino {
 #endif
 };
 
-constexpr int ZPAD = 2048;      // padding pixels read zeros from here (K <= ZPAD)
-// read-only: never written by any kernel or by the host (zero-initialised image in the code object, one per device)
-__device__ const float wino_zeros[ZPAD + 8] = {};
-
 __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
 }
 
-// Output transform + store + BatchNorm partial sums, shared by the register-direct and the LDS-staged kernels.  `toff[32]` (LDS):
+// Output transform + store + BatchNorm partial sums.  `toff[32]` (LDS):
 // pixel index of each tile's top-left output ((b H + 2 ty) W + 2 tx), -1 for an empty tile slot; `whole_tiles`: all 32 slots hold tiles
 // (wave-uniform); `tgrp`: the workgroup's row of the BatchNorm partial-sum table.  Every wave has passed a barrier after its last use
 // of `smem` before the call.
@@ -271,164 +265,6 @@ __device__ __forceinline__ void wino_epilogue(const Wino &g, f32x16 (&acc)[4][NT
             g.stats[((size_t)tgrp * 2 + 1) * g.N + n] = a1;
         }
     }
-}
-
-template <int NT, int PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE == 1 ? 2 : 1, PIPE == 1 ? (NT == 1 ? 3 : 2) : (PIPE == 3 && NT == 1 ? 2 : 1)))) void wino_kernel(const Wino g) {
-    constexpr int BNW = 32 * NT;
-    constexpr int TOFF = 4 * 2 * TPB * BNW + 256 * 2;              // tile offsets: behind everything either epilogue form uses
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // epilogue only: S[4][2][32][BNW] (+ stats) / images + tile offsets + stats
-
-#ifdef YH_WINO_STAMPS
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int lr = lane & 31, lh = lane >> 5;
-    // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): remap the linear id so that every
-    // XCD walks a contiguous range of (tile group, column block) pairs with the column blocks of one tile group
-    // adjacent -- the halo rows shared by vertically adjacent tile groups and the input re-read by the other column
-    // blocks then hit that XCD's L2 instead of going out to the fabric.  Bijective for any grid size.
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tgrp = lin / g.ncol, colb = lin - tgrp * g.ncol;
-    const int tile0 = tgrp * TPB, n0 = colb * BNW;
-
-    // rows of the 4x4 input patch that transform row xi = wave combines: t = d[ra] + sg * d[rb]
-    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
-    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
-    const float sg = wave == 1 ? 1.f : -1.f;
-
-    const gfloat *dp[2][4];                    // per-lane pixel pointers (global address space: see YH_GLOBAL); padding pixels point into wino_zeros
-    {
-        int tg = tile0 + lr;
-        bool tv = tg < g.ntiles;
-        if (!tv) tg = 0;
-        int b = fdiv(tg, g.tpi_magic, g.tpi_shift), r = tg - b * g.TPI;
-        int ty = fdiv(r, g.tw_magic, g.tw_shift), tx = r - ty * g.TW;
-        // pixel index of the tile's top-left output, for the training epilogue (read after its barrier; -1 = no such tile)
-        if (wave == 0 && lh == 0) ((int *)(smem + TOFF))[lr] = tv ? (b * g.H + 2 * ty) * g.W + 2 * tx : -1;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            int iy = 2 * ty - 1 + (rr ? rb : ra);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int ix = 2 * tx - 1 + c;
-                bool ok = tv && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                dp[rr][c] = (ok ? yh_global(g.in) + (size_t)((b * g.H + iy) * g.W + ix) * g.ldi : yh_global(&wino_zeros[0])) + 4 * lh;
-            }
-        }
-    }
-    // U fragment addresses: ((pos*(K/4) + kq) * ldu + n) * 4, pos = 4*wave + nu, kq = chunk*2 + lh
-    const int kq4 = g.K >> 2;
-    const float *ub[NT];
-    bool uok[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        int n = n0 + j * 32 + lr;
-        uok[j] = n < g.ldu;
-        ub[j] = g.U + ((size_t)((4 * wave) * kq4 + lh) * g.ldu + (uok[j] ? n : 0)) * 4;
-    }
-    const size_t upos = (size_t)kq4 * g.ldu * 4;      // stride between positions
-    const size_t uchunk = (size_t)2 * g.ldu * 4;      // stride between chunks
-
-    // Two register sets (A, B), loop unrolled by two: the loads of one set are in flight behind the MFMAs of the
-    // other.  No branches, selects or LDS in the loop.
-    f32x4 dA[2][4], uA[4][NT], dB[2][4], uB[4][NT], dC[2][4], uC[4][NT];      // dC / uC: PIPE == 3 only
-    auto load_chunk = [&](int c, f32x4 (&d)[2][4], f32x4 (&u)[4][NT]) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) d[rr][cc] = *(const YH_GLOBAL f32x4 *)(dp[rr][cc] + c * KC);
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) u[v][j] = *(const f32x4 *)(ub[j] + v * upos + c * uchunk);
-    };
-
-    f32x16 acc[4][NT];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
-
-    auto compute = [&](const f32x4 (&d)[2][4], const f32x4 (&u)[4][NT]) {
-        f32x4 tt[4], V[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) tt[cc] = d[0][cc] + sg * d[1][cc];
-        V[0] = tt[0] - tt[2];
-        V[1] = tt[1] + tt[2];
-        V[2] = tt[2] - tt[1];
-        V[3] = tt[1] - tt[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], u[v][j][e], acc[v][j], 0, 0, 0);
-    };
-    const int nchunks = g.K / KC;              // even (K % 16 == 0)
-#ifdef YH_WINO_STAMPS
-    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-#endif
-    if constexpr (PIPE == 3) {
-        // three register sets: the loads of chunk c + 2 are issued before the MFMAs of chunk c (two chunks = 4096 MFMA cycles of
-        // cover; one chunk left ~1100 cycles of every 3200 waiting at 1 wave per SIMD -- stamps, 64 -> 64 at 40x40)
-        const int last = nchunks - 1;
-        load_chunk(0, dA, uA);
-        load_chunk(1, dB, uB);
-        for (int c = 0; c < nchunks; c += 3) {
-            load_chunk(c + 2 < last ? c + 2 : last, dC, uC);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(dA, uA);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < nchunks) {
-                load_chunk(c + 3 < last ? c + 3 : last, dA, uA);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(dB, uB);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (c + 2 < nchunks) {
-                load_chunk(c + 4 < last ? c + 4 : last, dB, uB);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(dC, uC);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else if constexpr (PIPE == 2) {
-        load_chunk(0, dA, uA);
-        for (int c = 0; c < nchunks; c += 2) {
-            load_chunk(c + 1, dB, uB);
-            __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the MFMAs they hide behind
-            compute(dA, uA);
-            __builtin_amdgcn_sched_barrier(0);
-            load_chunk(c + 2 < nchunks ? c + 2 : c, dA, uA);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(dB, uB);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {                                       // one register set, two waves per SIMD hide each other's loads
-        for (int c = 0; c < nchunks; ++c) {
-            load_chunk(c, dA, uA);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(dA, uA);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-#ifdef YH_WINO_STAMPS
-    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
-#endif
-    wino_epilogue<NT>(g, acc, smem, (const int *)(smem + TOFF), tile0 + TPB <= g.ntiles, tgrp, n0);
-#ifdef YH_WINO_STAMPS
-    if (g.dbg && t == 0) {
-        unsigned long long *d = g.dbg + (size_t)blockIdx.x * 6;
-        d[0] = st0; d[1] = st1; d[2] = st2; d[3] = __builtin_amdgcn_s_memtime(); d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -914,12 +750,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 struct WinoWL {
     const float *x, *dy;
     float *ws;
+    const float *icoef;         // input prologue table of x ([scale | shift | gate], icoef_ld apart; see yh_prologue) or null
+    int icoef_ld;
     int ldx, lddy;
     int B, H, W, Cin, Cout;
     int TW, TH, G, spr, nstrips, sps;   // G tiles per strip (even), strips per tile row, total strips, strips per split
 };
 
-template <int NT>
+template <int NT, bool ACT>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_lds_kernel(const WinoWL g) {
     constexpr int GMAX = 16, PWMAX = 2 * GMAX + 2;
     constexpr int XPIECES_MAX = 4 * PWMAX * 8, DPIECES_MAX = 2 * 2 * GMAX * 8 * NT;
@@ -960,6 +798,14 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_lds_kernel(const WinoWL g) 
 #pragma unroll
     for (int k = 0; k < NDP; ++k) doff[k] = (drow[k] * g.W + dpix[k]) * g.lddy + 4 * dq[k];
     f32x4 rx[NXP], rd[NDP];
+    // input prologue: every x piece of this thread covers the same channel quad (256 % 8 == 0), so its coefficients are loaded once;
+    // padding must stay zero AFTER the activation: one validity bit per piece, refreshed by fetch
+    f32x4 psc, psh, pgt;
+    unsigned xok = 0;
+    if constexpr (ACT) {
+        const int ch = ci0 + 4 * (t & 7);
+        psc = *(const f32x4 *)(g.icoef + ch); psh = *(const f32x4 *)(g.icoef + g.icoef_ld + ch); pgt = *(const f32x4 *)(g.icoef + 2 * g.icoef_ld + ch);
+    }
     auto fetch = [&](int sid) {
         const int sx = sid % g.spr, rest = sid / g.spr;
         const int ty = rest % g.TH, b = rest / g.TH;
@@ -967,11 +813,14 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_lds_kernel(const WinoWL g) 
         const float *xbase = g.x + ((ptrdiff_t)(b * g.H + iy0) * g.W + ix0) * g.ldx + ci0;
         const float *dbase = g.dy + ((ptrdiff_t)(b * g.H + 2 * ty) * g.W + 2 * sx * G) * g.lddy + co0;
         const int wleft = g.W - 2 * sx * G;                // dY pixels of this strip that exist
+        xok = 0;
 #pragma unroll
         for (int k = 0; k < NXP; ++k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xrow[k] >= 0 && (unsigned)(iy0 + xrow[k]) < (unsigned)g.H && (unsigned)(ix0 + xpix[k]) < (unsigned)g.W)
+            if (xrow[k] >= 0 && (unsigned)(iy0 + xrow[k]) < (unsigned)g.H && (unsigned)(ix0 + xpix[k]) < (unsigned)g.W) {
                 v = *(const f32x4 *)(xbase + xoff[k]);
+                xok |= 1u << k;
+            }
             rx[k] = v;
         }
 #pragma unroll
@@ -984,7 +833,16 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_lds_kernel(const WinoWL g) 
     auto park = [&]() {
 #pragma unroll
         for (int k = 0; k < NXP; ++k)
-            if (xrow[k] >= 0) *(f32x4 *)(Xs + (xrow[k] * PWMAX + xpix[k]) * 32 + 4 * xq[k]) = rx[k];
+            if (xrow[k] >= 0) {
+                f32x4 v = rx[k];
+                if constexpr (ACT) {
+                    if (xok >> k & 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = yh_prologue(v[e], psc[e], psh[e], pgt[e]);
+                    }
+                }
+                *(f32x4 *)(Xs + (xrow[k] * PWMAX + xpix[k]) * 32 + 4 * xq[k]) = v;
+            }
 #pragma unroll
         for (int k = 0; k < NDP; ++k)
             if (drow[k] >= 0) *(f32x4 *)(Ds + (drow[k] * 2 * GMAX + dpix[k]) * BNW + 4 * dq[k]) = rd[k];
@@ -1091,64 +949,6 @@ void set_magic(unsigned d, unsigned &magic, int &shift) {
     magic = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
     shift = l - 1;
 }
-
-template <int NT, int PIPE>
-int launch_nt(Wino &g, hipStream_t st) {
-    constexpr int BNW = 32 * NT;
-    g.ncol = cdiv(g.N, BNW);
-    constexpr size_t smem = (size_t)(4 * 2 * TPB * BNW + 256 * 2 + TPB) * sizeof(float);
-    if (int rc = yh_ensure_dyn_smem((const void *)wino_kernel<NT, PIPE>, smem)) return rc;
-#ifdef YH_WINO_STAMPS
-    static unsigned long long *dbgbuf = nullptr;
-    const int nwg_dbg = cdiv(g.ntiles, TPB) * g.ncol;
-    if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
-    g.dbg = getenv("YH_WINO_DBG") && (size_t)nwg_dbg * 48 <= ((size_t)1 << 24) ? dbgbuf : nullptr;
-#endif
-    hipLaunchKernelGGL((wino_kernel<NT, PIPE>), dim3(cdiv(g.ntiles, TPB) * g.ncol), dim3(256), smem, st, g);
-    YH_CHECK_LAUNCH("wino");
-#ifdef YH_WINO_STAMPS
-    if (g.dbg) {
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)nwg_dbg * 6);
-        (void)hipMemcpy(h.data(), g.dbg, h.size() * 8, hipMemcpyDeviceToHost);
-        double a = 0, b = 0, c = 0, rt = 0; unsigned long long lo = ~0ull, hi = 0;
-        for (int i = 0; i < nwg_dbg; ++i) {
-            a += (double)(h[6 * i + 1] - h[6 * i]); b += (double)(h[6 * i + 2] - h[6 * i + 1]); c += (double)(h[6 * i + 3] - h[6 * i + 2]);
-            rt += (double)(h[6 * i + 5] - h[6 * i + 4]);
-            if (h[6 * i + 4] < lo) lo = h[6 * i + 4];
-            if (h[6 * i + 5] > hi) hi = h[6 * i + 5];
-        }
-        const double mf = (double)(g.K / 8) * 16 * NT * 64;
-        fprintf(stderr, "[wino stamps] NT %d PIPE %d K %d N %d wgs %d: setup %.0f, loop %.0f (MFMA issue floor %.0f), epilogue %.0f cycles per workgroup = %.2f us (clock %.2f GHz); span %.1f us\n",
-                NT, PIPE, g.K, g.N, nwg_dbg, a / nwg_dbg, b / nwg_dbg, mf, c / nwg_dbg, rt / nwg_dbg / 100.0, (a + b + c) / rt * 0.1, (double)(hi - lo) / 100.0);
-    }
-#endif
-    return 0;
-}
-
-int launch_wino(Wino &g, hipStream_t st) {
-    YH_REQUIRE(g.H % 2 == 0 && g.W % 2 == 0, "conv_wino: H and W must be even");
-    YH_REQUIRE(g.K % (2 * KC) == 0 && g.K <= ZPAD && g.ldi % 4 == 0 && (((uintptr_t)g.in | (uintptr_t)g.U) & 15) == 0 && g.ldu >= g.N,
-               "conv_wino: K must be a multiple of 16 (<= 2048), buffers 16-byte addressable");
-    YH_REQUIRE((int64_t)g.B * g.H * g.W * g.ldi < (1ll << 31) && (int64_t)g.B * g.H * g.W * g.ldo * (g.up2 ? 4 : 1) < (1ll << 31),
-               "conv_wino: tensors exceed 32-bit element offsets");
-    g.TW = g.W / 2; g.TPI = (g.H / 2) * g.TW; g.ntiles = g.B * g.TPI;
-    set_magic((unsigned)g.TW, g.tw_magic, g.tw_shift);
-    set_magic((unsigned)g.TPI, g.tpi_magic, g.tpi_shift);
-    // Enough tile groups (>= 800: the 160^2 ... 40^2 layers at batch 64): one register set at two waves per SIMD, the two
-    // resident workgroups of a CU hide each other's loads and epilogue (loop at 83 % of the MFMA issue rate by in-kernel
-    // stamps); fewer (20^2 layers): the software-pipelined variant at one wave per SIMD.  Measured after the FLAT -> global
-    // load fix, forward ms at batch 64 (PIPE 1 / 2 / 3): 80^2 64->64 0.200 / 0.241 / 0.246, 40^2 64->64 0.065 / 0.071 / 0.074,
-    // 40^2 128->128 0.183 / 0.189 / 0.195, 20^2 128->128 0.059 / 0.053 / 0.057, 20^2 256->256 0.199 / 0.183 / 0.188.
-    // Three register sets (prefetch distance 2) never win: what is left of the loop's stall at one wave per SIMD is not
-    // load latency (the strided 16-byte activation loads keep the L1 fill path busy).  Also dropped: compiler-scheduled or
-    // sched_group_barrier-interleaved loads among the MFMAs (15-25 % slower than loads pinned ahead of them).
-    constexpr int force = 0;
-    const int pipe = force ? force : (cdiv(g.ntiles, TPB) >= 800 ? 1 : 2);
-    if (g.N <= 32) return pipe == 3 ? launch_nt<1, 3>(g, st) : pipe == 2 ? launch_nt<1, 2>(g, st) : launch_nt<1, 1>(g, st);
-    return pipe == 3 ? launch_nt<2, 3>(g, st) : pipe == 2 ? launch_nt<2, 2>(g, st) : launch_nt<2, 1>(g, st);
-}
-
 
 // ---- LDS-staged kernel: block geometry ------------------------------------------------------------------------------------
 // R x C tiles per workgroup (R C <= 32) over B*TH linear tile rows x TW tile columns: the fewest workgroups (= the fewest MFMA
@@ -1324,9 +1124,21 @@ extern "C" int64_t yh_conv_wino_bwd_weight_ws(int B, int H, int W, int Cin, int 
     return (int64_t)(nsplit > nsplit2 ? nsplit : nsplit2) * 9 * Cin * Cout;       // either kernel may run (YH_WINO_WGRAD_LDS)
 }
 
+static int wino_bwd_weight_impl(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                                int64_t ws_floats, int B, int H, int W, int Cin, int Cout, void *stream);
 extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy, int lddy, float *dw, float *ws, int64_t ws_floats,
                                        int B, int H, int W, int Cin, int Cout, void *stream) {
+    return wino_bwd_weight_impl(x, ldx, nullptr, 0, dy, lddy, dw, ws, ws_floats, B, H, W, Cin, Cout, stream);
+}
+extern "C" int yh_conv_wino_bwd_weight_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw,
+                                           float *ws, int64_t ws_floats, int B, int H, int W, int Cin, int Cout, void *stream) {
+    return wino_bwd_weight_impl(x, ldx, icoef, icoef_ld, dy, lddy, dw, ws, ws_floats, B, H, W, Cin, Cout, stream);
+}
+static int wino_bwd_weight_impl(const float *x, int ldx, const float *icoef, int icoef_ld, const float *dy, int lddy, float *dw, float *ws,
+                                int64_t ws_floats, int B, int H, int W, int Cin, int Cout, void *stream) {
     YH_REQUIRE(x && dy && dw && ws && ldx >= Cin && lddy >= Cout, "conv_wino_bwd_weight: bad argument");
+    YH_REQUIRE(!icoef || ((((uintptr_t)icoef) & 15) == 0 && icoef_ld % 4 == 0 && icoef_ld >= Cin),
+               "conv_wino_bwd_weight: the input prologue table must be 16-byte aligned with a stride that is a multiple of 4");
     WinoW g{};
     int nsplit, NT;
     int rc = wgrad_plan(g, nsplit, NT, B, H, W, Cin, Cout);
@@ -1346,18 +1158,24 @@ extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy,
         int ns2, NT2;
         wgrad_lds_plan(gl, ns2, NT2, B, H, W, Cin, Cout);
         YH_REQUIRE(ws_floats >= (int64_t)ns2 * 9 * Cin * Cout, "conv_wino_bwd_weight: workspace too small");
-        gl.x = x; gl.dy = dy; gl.ws = ws; gl.ldx = ldx; gl.lddy = lddy;
+        gl.x = x; gl.dy = dy; gl.ws = ws; gl.ldx = ldx; gl.lddy = lddy; gl.icoef = icoef; gl.icoef_ld = icoef_ld;
         dim3 grid2(ns2, Cin / 32, Cout / (32 * NT2));
         const size_t stage = (size_t)(4 * 34 * 32 + 2 * 32 * 32 * NT2) * sizeof(float), epi = (size_t)4 * 32 * 32 * NT2 * sizeof(float);
         const size_t smem2 = stage > epi ? stage : epi;
-        if (NT2 == 2) hipLaunchKernelGGL((wino_wgrad_lds_kernel<2>), grid2, dim3(256), smem2, st, gl);
-        else hipLaunchKernelGGL((wino_wgrad_lds_kernel<1>), grid2, dim3(256), smem2, st, gl);
+        if (icoef) {
+            if (NT2 == 2) hipLaunchKernelGGL((wino_wgrad_lds_kernel<2, true>), grid2, dim3(256), smem2, st, gl);
+            else hipLaunchKernelGGL((wino_wgrad_lds_kernel<1, true>), grid2, dim3(256), smem2, st, gl);
+        } else {
+            if (NT2 == 2) hipLaunchKernelGGL((wino_wgrad_lds_kernel<2, false>), grid2, dim3(256), smem2, st, gl);
+            else hipLaunchKernelGGL((wino_wgrad_lds_kernel<1, false>), grid2, dim3(256), smem2, st, gl);
+        }
         YH_CHECK_LAUNCH("wino_wgrad_lds");
         const int n2 = 9 * Cin * Cout;
         hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n2, 16)), dim3(256), 0, st, ws, dw, ns2, Cin, Cout);
         YH_CHECK_LAUNCH("wino_wgrad_reduce");
         return 0;
     }
+    YH_REQUIRE(!icoef, "conv_wino_bwd_weight: the input prologue needs 16-byte addressable views (LDS-staged kernel)");
     dim3 grid(nsplit, Cin / 32, Cout / (32 * NT));
     // two waves per SIMD hide each other's address arithmetic for the 64-column variant (0.222 -> 0.187 ms on 64->64 @80^2);
     // the 32-column variant spills at that register budget and stays at one
@@ -1371,7 +1189,6 @@ extern "C" int yh_conv_wino_bwd_weight(const float *x, int ldx, const float *dy,
     return 0;
 }
 
-extern "C" int yh_conv_wino_blocks(int B, int H, int W) { return cdiv(B * (H / 2) * (W / 2), TPB); }
 
 extern "C" int yh_wino_weights(const float *oihw, float *U, int Cout, int Cin, int ldu, int backward, void *stream) {
     YH_REQUIRE(oihw && U && Cout > 0 && Cin > 0 && ldu >= (backward ? Cin : Cout) && (backward ? Cout : Cin) % 4 == 0, "wino_weights: bad argument");
@@ -1397,7 +1214,7 @@ extern "C" int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu
     Wino g{};
     g.in = x; g.U = U; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.ldi = ldx; g.ldu = ldu; g.ldo = ldy; g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = Cout; g.accumulate = 0;
-    return launch_wino(g, (hipStream_t)stream);
+    return launch_wino_lds(g, (hipStream_t)stream);
 }
 
 extern "C" int yh_conv_wino_fwd_fused(const float *x, int ldx, const float *U, int ldu, const float *bias, const float *res, int ldr,
@@ -1408,7 +1225,7 @@ extern "C" int yh_conv_wino_fwd_fused(const float *x, int ldx, const float *U, i
     g.in = x; g.U = U; g.bias = bias; g.out = y; g.stats = nullptr;
     g.ldi = ldx; g.ldu = ldu; g.ldo = ldy; g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = Cout; g.accumulate = 0;
     g.res = res; g.ldr = ldr; g.act = act_silu ? 1 : 0; g.up2 = upsample ? 1 : 0;
-    return launch_wino(g, (hipStream_t)stream);
+    return launch_wino_lds(g, (hipStream_t)stream);
 }
 
 extern "C" int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
@@ -1417,10 +1234,10 @@ extern "C" int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub,
     Wino g{};
     g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
     g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
-    return launch_wino(g, (hipStream_t)stream);
+    return launch_wino_lds(g, (hipStream_t)stream);
 }
 
-extern "C" int yh_conv_wino_lds_blocks(int B, int H, int W) {
+extern "C" int yh_conv_wino_blocks(int B, int H, int W) {
     WinoGeom gm{};
     if (H <= 0 || W <= 0 || B <= 0 || (H | W) & 1 || !wino_lds_geom(B, H / 2, W / 2, gm)) return -1;
     return gm.nrb * gm.ncb;
@@ -1436,11 +1253,3 @@ extern "C" int yh_conv_wino_fwd_act(const float *x, int ldx, const float *icoef,
     return launch_wino_lds(g, (hipStream_t)stream);
 }
 
-extern "C" int yh_conv_wino_bwd_data_lds(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
-                                         int W, int Cin, int Cout, int accumulate, void *stream) {
-    YH_REQUIRE(dy && Ub && dx && B > 0 && H > 0 && W > 0 && lddy >= Cout && lddx >= Cin, "conv_wino_bwd_data_lds: bad argument");
-    Wino g{};
-    g.in = dy; g.U = Ub; g.bias = nullptr; g.out = dx; g.stats = nullptr;
-    g.ldi = lddy; g.ldu = ldub; g.ldo = lddx; g.B = B; g.H = H; g.W = W; g.K = Cout; g.N = Cin; g.accumulate = accumulate;
-    return launch_wino_lds(g, (hipStream_t)stream);
-}

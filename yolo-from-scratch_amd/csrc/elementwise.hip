@@ -245,7 +245,8 @@ __global__ void colsum_stage2(const float *__restrict__ part, int nblk, int C, f
 __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, double count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
-                                   float *__restrict__ coef, int C, int64_t *__restrict__ nbt) {
+                                   float *__restrict__ coef, int C, int64_t *__restrict__ nbt,
+                                   float *__restrict__ xscale, float *__restrict__ xshift) {
     __shared__ double rs[16], rq[16];
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
@@ -269,6 +270,10 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, dou
         coef[C + c] = beta[c] - (float)mean * scale;
         coef[2 * C + c] = (float)mean;
         coef[3 * C + c] = invstd;
+        if (xscale) {            // rows of the CONSUMERS' input-prologue table (the activation is applied where it is read)
+            xscale[c] = scale;
+            xshift[c] = beta[c] - (float)mean * scale;
+        }
         if (rmean) {
             double unb = count > 1.0 ? var * count / (count - 1.0) : var;
             rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
@@ -317,8 +322,18 @@ template <> __device__ __forceinline__ void stg<8>(bf16 *p, f32x8 v) { *(bf16x8 
 template <typename T, int G>
 __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const T *__restrict__ y, int ldy, const float *__restrict__ coef,
                                    const T *__restrict__ res, int ldr, T *__restrict__ out, int ldo,
-                                   int64_t M, int C, int H, int W, int upsample) {
+                                   int64_t M, int C, int H, int W, int upsample, const float *__restrict__ rcoef, int rcoef_ld) {
     typedef typename VecOf<G>::type V;
+    // rcoef: the residual tensor was never materialised either -- `res` holds its producer's raw convolution output and the
+    // prologue table rows [scale | shift | gate] (rcoef_ld apart) turn it into the activation here (see yh_prologue)
+    auto resv = [&](int64_t mm, int c) __attribute__((always_inline)) {
+        V r = ldg<G>(res + mm * ldr + c);
+        if (rcoef) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) r[e] = yh_prologue(r[e], rcoef[c + e], rcoef[rcoef_ld + c + e], rcoef[2 * rcoef_ld + c + e]);
+        }
+        return r;
+    };
     // (row, channel-group) cursor advanced incrementally: the grid-stride index i = m * cq + c4 is never divided inside
     // the loop (a 64-bit division per group cost more VALU time than the sigmoids)
     const int cq = C / G;
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const T *__restrict__ 
         for (; m + dm < M; m += 2 * dm) {
             const V v0 = ldg<G>(y + m * ldy + c), v1 = ldg<G>(y + (m + dm) * ldy + c);
             V r0, r1;
-            if (res) { r0 = ldg<G>(res + m * ldr + c); r1 = ldg<G>(res + (m + dm) * ldr + c); }
+            if (res) { r0 = resv(m, c); r1 = resv(m + dm, c); }
             V a0, a1;
 #pragma unroll
             for (int e = 0; e < G; ++e) a0[e] = silu_f(v0[e] * sc[e] + sh[e]);
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const T *__restrict__ 
             V a;
 #pragma unroll
             for (int e = 0; e < G; ++e) a[e] = silu_f(v[e] * sc[e] + sh[e]);
-            if (res) a += ldg<G>(res + m * ldr + c);
+            if (res) a += resv(m, c);
             finish(m, c, a);
         }
         return;
@@ -378,10 +393,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const T *__restrict__ 
         V a;
 #pragma unroll
         for (int e = 0; e < G; ++e) a[e] = silu_f(v[e] * sc[e] + sh[e]);
-        if (res) {
-            V r = ldg<G>(res + m * ldr + c);
-            a += r;
-        }
+        if (res) a += resv(m, c);
         finish(m, c, a);
     }
 }
@@ -760,14 +772,20 @@ extern "C" int yh_bf16_colsum(const void *x, int ldx, int64_t M, int C, float *o
     return colsum_t<bf16>((const bf16 *)x, ldx, M, C, out, ws, stream);
 }
 
+extern "C" int yh_bn_finalize_x(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
+                                int64_t *num_batches_tracked, float *xscale, float *xshift, void *stream) {
+    YH_REQUIRE(partials && gamma && beta && coef && nblk > 0 && count > 0 && C > 0 && !xscale == !xshift, "bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, (double)count,
+                       gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked, xscale, xshift);
+    YH_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
 extern "C" int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
                               float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
                               int64_t *num_batches_tracked, void *stream) {
-    YH_REQUIRE(partials && gamma && beta && coef && nblk > 0 && count > 0 && C > 0, "bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, (double)count,
-                       gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked);
-    YH_CHECK_LAUNCH("bn_finalize");
-    return 0;
+    return yh_bn_finalize_x(partials, nblk, count, gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked,
+                            nullptr, nullptr, stream);
 }
 
 extern "C" int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean,
@@ -800,26 +818,30 @@ static bool wide_groups(int C, std::initializer_list<int> lds, std::initializer_
 
 template <typename T>
 static int bn_silu_fwd_t(const T *y, int ldy, const float *coef, const T *residual, int ldr, T *out, int ldo, int64_t M, int C,
-                         int H, int W, int upsample, void *stream) {
-    YH_REQUIRE(y && coef && out && M > 0 && M < (1ll << 31), "bn_silu_fwd: bad argument");
+                         int H, int W, int upsample, const float *rcoef, int rcoef_ld, void *stream) {
+    YH_REQUIRE(y && coef && out && M > 0 && M < (1ll << 31) && (!rcoef || (residual && rcoef_ld >= C)), "bn_silu_fwd: bad argument");
     YH_REQ_VEC4("bn_silu_fwd", C, ldy, ldo, residual ? ldr : 0);
     YH_REQUIRE(!upsample || (H > 0 && W > 0 && M % ((int64_t)H * W) == 0), "bn_silu_fwd: upsample needs H, W");
     if (wide_groups<T>(C, {ldy, ldo, residual ? ldr : 0}, {y, out, residual}))
         hipLaunchKernelGGL((bn_silu_fwd_kernel<T, 8>), dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
-                           residual, ldr, out, ldo, M, C, H, W, upsample);
+                           residual, ldr, out, ldo, M, C, H, W, upsample, rcoef, rcoef_ld);
     else
         hipLaunchKernelGGL((bn_silu_fwd_kernel<T, 4>), dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, coef,
-                           residual, ldr, out, ldo, M, C, H, W, upsample);
+                           residual, ldr, out, ldo, M, C, H, W, upsample, rcoef, rcoef_ld);
     YH_CHECK_LAUNCH("bn_silu_fwd");
     return 0;
 }
 extern "C" int yh_bn_silu_fwd(const float *y, int ldy, const float *coef, const float *residual, int ldr, float *out,
                               int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
-    return bn_silu_fwd_t<float>(y, ldy, coef, residual, ldr, out, ldo, M, C, H, W, upsample, stream);
+    return bn_silu_fwd_t<float>(y, ldy, coef, residual, ldr, out, ldo, M, C, H, W, upsample, nullptr, 0, stream);
+}
+extern "C" int yh_bn_silu_fwd_res(const float *y, int ldy, const float *coef, const float *residual, int ldr, const float *rcoef,
+                                  int rcoef_ld, float *out, int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_fwd_t<float>(y, ldy, coef, residual, ldr, out, ldo, M, C, H, W, upsample, rcoef, rcoef_ld, stream);
 }
 extern "C" int yh_bf16_bn_silu_fwd(const void *y, int ldy, const float *coef, const void *residual, int ldr, void *out,
                                    int ldo, int64_t M, int C, int H, int W, int upsample, void *stream) {
-    return bn_silu_fwd_t<bf16>((const bf16 *)y, ldy, coef, (const bf16 *)residual, ldr, (bf16 *)out, ldo, M, C, H, W, upsample, stream);
+    return bn_silu_fwd_t<bf16>((const bf16 *)y, ldy, coef, (const bf16 *)residual, ldr, (bf16 *)out, ldo, M, C, H, W, upsample, nullptr, 0, stream);
 }
 
 extern "C" int yh_bn_bwd_blocks(int64_t M, int C) {

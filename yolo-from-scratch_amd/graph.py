@@ -66,6 +66,20 @@ class Buffer:
         self.data = torch.empty(B, H, W, C, device=plan.device, dtype=self.dtype)
         self._grad: Optional[torch.Tensor] = None
         self.grad_cover: List[Tuple[int, int]] = []   # channel ranges already written in this backward
+        self._icoef: Optional[torch.Tensor] = None
+
+    @property
+    def icoef(self) -> torch.Tensor:
+        """Input-prologue table of the buffer's channels, rows [scale | shift | gate] (see yh_prologue in csrc/common.h): channels
+        whose producer's BatchNorm + SiLU is applied by the READERS (the activation is never materialised, the buffer holds the raw
+        convolution output) carry the producer's scale / shift (rewritten by its bn_finalize every step) and gate 1; all others
+        the identity (1, 0, gate 0)."""
+        if self._icoef is None:
+            ld = _rup4(self.C) + 4
+            t = torch.zeros(3, ld, device=self.plan.device, dtype=torch.float32)
+            t[0].fill_(1.0)
+            self._icoef = t
+        return self._icoef
 
     @property
     def grad(self) -> torch.Tensor:
@@ -97,6 +111,9 @@ class View:
     def M(self): return self.buf.B * self.buf.H * self.buf.W
     def ptr(self) -> int: return self.buf.data.data_ptr() + self.buf.data.element_size() * self.off
     def gptr(self) -> int: return self.buf.grad.data_ptr() + self.buf.grad.element_size() * self.off
+    def icoef_ptr(self, row: int = 0) -> int: return self.buf.icoef.data_ptr() + 4 * (row * self.buf.icoef.shape[1] + self.off)
+    @property
+    def icoef_ld(self) -> int: return self.buf.icoef.shape[1]
 
 
 def _same_view(a: "View", b: "View") -> bool:
@@ -145,6 +162,12 @@ class ConvRec:
     pair: Optional["ConvRec"] = None       # sibling pointwise conv reading the same input (fused backward-data)
     pair_first: bool = False
     conv: Optional[torch.nn.Conv2d] = None  # the parameter container (staleness checks look the parameters up again)
+    virtual: bool = False   # the activation is never materialised: the conv writes its raw output into `out`, readers apply BN + SiLU
+    x_fused: bool = False   # the input view has virtual channels: forward / weight-gradient kernels run the input prologue
+    yp: int = 0             # address and pixel stride of the raw conv output (private tensor `y`, or the `out` view when virtual)
+    ldy: int = 0
+    dyp: int = 0            # where the BatchNorm backward writes dY: over Y in place, or (virtual) into the private tensor `y` -- the
+    lddy: int = 0           # raw output in the shared buffer is still being read by the consumers' weight gradients on the side lane
 
 
 @dataclass
@@ -273,6 +296,124 @@ class Plan:
                         out.append(p)
         return out
 
+    # ---- kernel-family routing (fp32 training plans) ---------------------------------------------------------------------
+    def _route_f32(self, r: "ConvRec", special: bool):
+        """Which kernel family runs each pass of one convolution.  Decided for every record BEFORE anything is lowered: the fusion
+        planner (_plan_fusion) needs to know whether every reader of a tensor can apply the producer's BatchNorm + SiLU itself."""
+        lib = L.lib()
+        use_wino = use_pw = use_pwg = use_s2m = use_narrow = special
+        r.ldwb = _rup4(r.cin)
+        r.ldwf = _rup4(r.cout)
+        r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
+        wino_ok = use_wino and r.k == 3 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.x.ld % 4 == 0
+        r.wino_f = wino_ok and r.cin % 16 == 0 and r.cin <= 2048
+        r.wino_b = wino_ok and r.need_dx and r.cout % 16 == 0 and r.cout <= 2048
+        r.wino_w = wino_ok and r.cin % 32 == 0 and r.cout % 32 == 0 and r.x.W >= 4
+        r.pw_w = use_pw and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1]
+        # pointwise GEMM kernels: measured faster than the gather-GEMM except when both K and N are >= 256
+        pw_ok = use_pwg and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0
+        r.pw_f = pw_ok and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256)
+        r.s2m_b = use_s2m and r.k == 3 and r.s == 2 and r.need_dx and r.cin <= 16 and r.x.ld == r.cin and r.x.W % 2 == 0 \
+            and r.cin == r.weight.shape[1]
+        # narrow high-resolution 3x3 layers: direct kernel (LDS halo patch, filter in registers, 16-wide MFMA tiles)
+        nar_ok = use_narrow and r.k == 3 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and r.x.off % 4 == 0
+        r.narrow_f = bool(nar_ok and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s))
+        if use_narrow and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16 \
+                and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s):
+            r.narrow_f = True                     # first layer: the same direct MFMA kernel with CIN = 4 (padded) channels
+        r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
+        if r.narrow_f:
+            r.wino_f = False
+        if r.narrow_b:
+            r.wino_b = False
+        if nar_ok and r.s == 2 and r.need_dx and lib.yh_conv_narrow_dgrad_s2_ok(r.cin, r.cout):
+            r.narrow_b, r.s2m_b = True, False      # the stride-2 form of the direct backward-data kernel
+        r.narrow_w = bool(use_narrow and r.k == 3 and r.x.ld % 4 == 0
+                          and r.x.off % 4 == 0 and lib.yh_conv_narrow_bwd_weight_ok(r.cin, r.weight.shape[1], r.cout, 3, r.s))
+        if r.narrow_w:
+            r.wino_w = False
+        if r.pair is None:
+            r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
+        elif r.pair_first:
+            kpair = r.cout + r.pair.cout
+            r.pw_b = r.pair.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and r.pair.cout % 8 == 0 and \
+                not (kpair >= 256 and r.cin >= 256)
+
+    def _plan_fusion(self, special: bool):
+        """Decide which Conv+BN+SiLU outputs are never materialised ("virtual"): the convolution writes its RAW output straight
+        into the output view (a channel slice of the consumer's buffer), bn_finalize publishes scale / shift in the buffer's
+        prologue table, and every reader -- forward kernel, weight-gradient kernel, residual add -- applies scale, shift and SiLU
+        while it stages its operand (train.py:253-265 executed at the consumer).  Saves the whole bn_silu_fwd round trip (8 bytes
+        per element fp32).  A tensor stays materialised when it carries a residual or an upsample, is a plan output, feeds a
+        max-pool, or has a reader whose kernel family has no prologue."""
+        readers: Dict[int, List[tuple]] = {}
+        for r in self.recs:
+            if isinstance(r, ConvRec):
+                readers.setdefault(id(r.x.buf), []).append((r.x.off, r.x.C, "conv", r))
+                if r.residual is not None:
+                    readers.setdefault(id(r.residual.buf), []).append((r.residual.off, r.residual.C, "res", r))
+            elif isinstance(r, PoolRec):
+                readers.setdefault(id(r.x.buf), []).append((r.x.off, r.x.C, "pool", r))
+        outs = [(id(v.buf), v.off, v.C) for v, _ in self.outputs]
+        enabled = special and os.environ.get("YH_FUSE_ACT", "1") != "0"
+
+        def overlap(o1, c1, o2, c2):
+            return o1 < o2 + c2 and o2 < o1 + c1
+        for r in self.recs:
+            if not isinstance(r, ConvRec) or r.bn is None:
+                continue
+            v = r.out
+            ok = enabled and self.training and not self.bf16 and not r.upsample and r.residual is None and v.off % 4 == 0 and v.C % 4 == 0
+            ok = ok and not any(b == id(v.buf) and overlap(v.off, v.C, o, c) for b, o, c in outs)
+            n_read = 0
+            for off, C, kind, c in readers.get(id(v.buf), []):
+                if not ok or not overlap(v.off, v.C, off, C):
+                    continue
+                n_read += 1
+                if kind == "pool":
+                    ok = False
+                elif kind == "conv":
+                    ok = self._fwd_prologue_ok(c) and self._wgrad_prologue_ok(c)
+            r.virtual = bool(ok and n_read > 0)
+        for r in self.recs:                      # readers of virtual channels
+            if isinstance(r, ConvRec):
+                r.x_fused = any(isinstance(q, ConvRec) and q.virtual and q.out.buf is r.x.buf and overlap(q.out.off, q.out.C, r.x.off, r.x.C)
+                                for q in self.recs)
+        for r in self.recs:
+            if isinstance(r, ConvRec) and r.virtual:
+                r.out.buf.icoef[2, r.out.off: r.out.off + r.out.C] = 1.0
+
+    def _fwd_prologue_ok(self, c: "ConvRec") -> bool:
+        """Forward kernel families that can apply the producer's BatchNorm + SiLU while staging their input."""
+        lib = L.lib()
+        if c.x.off % 4 or c.x.ld % 4 or c.cin % 4 or c.cin != c.weight.shape[1]:
+            return False
+        M = c.x.B * c.Ho * c.Wo
+        if c.narrow_f:
+            return c.cin == 16
+        if c.wino_f:
+            return True
+        if c.fwd2:
+            return bool(lib.yh_conv_pw_prologue_ok(M, c.cin, c.cout + c.pair.cout))
+        if c.pw_f:
+            return bool(lib.yh_conv_pw_prologue_ok(M, c.cin, c.cout))
+        return True                                   # gather-GEMM: 16-byte staging of 4-channel pieces
+
+    def _wgrad_prologue_ok(self, c: "ConvRec") -> bool:
+        lib = L.lib()
+        if c.x.off % 4 or c.x.ld % 4 or c.cin % 4 or c.cin != c.weight.shape[1]:
+            return False
+        if c.narrow_w:
+            return c.cin == 16
+        if c.wino_w or c.pw_w:
+            return True
+        return bool(lib.yh_conv_bwd_weight_prologue_ok(c.x.B, c.x.H, c.x.W, c.cin, c.cout, c.k, c.s))
+
+    def _res_fused(self, r: "ConvRec") -> bool:
+        v = r.residual
+        return v is not None and any(isinstance(q, ConvRec) and q.virtual and q.out.buf is v.buf and
+                                     q.out.off < v.off + v.C and v.off < q.out.off + q.out.C for q in self.recs)
+
     def compile(self, grad_of: Optional[Dict[int, torch.Tensor]] = None):
         """Allocate per-layer scratch and emit the op lists.  grad_of maps id(param) -> tensor that
         receives its gradient (views of a flat buffer); required when training."""
@@ -307,6 +448,11 @@ class Plan:
                     a.fwd2 = grp[1].fwd2 = (  # can order the fused launch before a side-lane fork
                         use_pwg and a.cin == a.weight.shape[1] and a.x.ld % 4 == 0 and a.cin % 8 == 0
                         and not (a.cin >= 256 and a.cout >= 256))
+        if self.training:
+            for r in self.recs:
+                if isinstance(r, ConvRec):
+                    self._route_f32(r, special)
+            self._plan_fusion(special)
         deferred_fork = False
         for ri, r in enumerate(self.recs):
             if isinstance(r, SyncRec):
@@ -320,7 +466,8 @@ class Plan:
             if isinstance(r, ConvRec):
                 kk = r.k * r.k
                 fused_second = r.fwd2 and r.pair is not None and not r.pair_first and r.wf is not None   # shares its sibling's matrix
-                r.ldwb = _rup4(r.cin)
+                if not self.training:
+                    r.ldwb = _rup4(r.cin)
                 if not fused_second:
                     r.ldwf = _rup4(r.cout)
                     r.wf = torch.empty(kk * r.cin * r.ldwf, **f32)
@@ -369,40 +516,6 @@ class Plan:
                                        p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr(), sws],
                                        l=[nws], **args))
                     continue
-                r.need_dx = self.training and (self.need_input_grad or r.x.buf is not self.input)
-                wino_ok = use_wino and r.k == 3 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.H % 2 == 0 and r.x.W % 2 == 0 and r.x.ld % 4 == 0
-                r.wino_f = wino_ok and r.cin % 16 == 0 and r.cin <= 2048
-                r.wino_b = wino_ok and r.need_dx and r.cout % 16 == 0 and r.cout <= 2048
-                r.wino_w = wino_ok and r.cin % 32 == 0 and r.cout % 32 == 0 and r.x.W >= 4
-                r.pw_w = use_pw and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1]
-                # pointwise GEMM kernels: measured faster than the gather-GEMM except when both K and N are >= 256
-                pw_ok = use_pwg and r.k == 1 and r.s == 1 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0
-                r.pw_f = pw_ok and r.cin % 8 == 0 and not (r.cin >= 256 and r.cout >= 256)
-                r.s2m_b = use_s2m and r.k == 3 and r.s == 2 and r.need_dx and r.cin <= 16 and r.x.ld == r.cin and r.x.W % 2 == 0 \
-                    and r.cin == r.weight.shape[1]
-                # narrow high-resolution 3x3 layers: direct kernel (LDS halo patch, filter in registers, 16-wide MFMA tiles)
-                nar_ok = use_narrow and r.k == 3 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and r.x.off % 4 == 0
-                r.narrow_f = bool(nar_ok and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s))
-                if use_narrow and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16 \
-                        and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s):
-                    r.narrow_f = True                     # first layer: the same direct MFMA kernel with CIN = 4 (padded) channels
-                r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
-                if r.narrow_f:
-                    r.wino_f = False
-                if r.narrow_b:
-                    r.wino_b = False
-                if nar_ok and r.s == 2 and r.need_dx and lib.yh_conv_narrow_dgrad_s2_ok(r.cin, r.cout):
-                    r.narrow_b, r.s2m_b = True, False      # the stride-2 form of the direct backward-data kernel
-                r.narrow_w = bool(use_narrow and r.k == 3 and r.x.ld % 4 == 0
-                                  and r.x.off % 4 == 0 and lib.yh_conv_narrow_bwd_weight_ok(r.cin, r.weight.shape[1], r.cout, 3, r.s))
-                if r.narrow_w:
-                    r.wino_w = False
-                if r.pair is None:
-                    r.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and not (r.cout >= 256 and r.cin >= 256)
-                elif r.pair_first:
-                    kpair = r.cout + r.pair.cout
-                    r.pw_b = r.pair.pw_b = pw_ok and r.need_dx and r.cout % 8 == 0 and r.pair.cout % 8 == 0 and \
-                        not (kpair >= 256 and r.cin >= 256)
                 if r.pair is not None and r.need_dx:
                     if r.pair_first:      # stacked backward packs: rows [0, c1) this conv, [c1, c1 + c2) its sibling
                         stacked = torch.empty((r.cout + r.pair.cout) * r.ldwb, **f32)
@@ -443,8 +556,13 @@ class Plan:
 
                 def alloc_out(c: ConvRec, nblk: int):        # raw conv output, BN coefficients and partial-sum scratch
                     c.nblk = nblk
-                    if c.bn is not None and c.y is None:
+                    if c.bn is not None and c.coef is None:
                         c.y = torch.empty(c.x.B, c.Ho, c.Wo, c.cout, **f32)
+                        c.dyp, c.lddy = c.y.data_ptr(), c.cout
+                        if c.virtual:                         # the raw output lives in the output view itself (never normalised in memory)
+                            c.yp, c.ldy = c.out.ptr(), c.out.ld
+                        else:
+                            c.yp, c.ldy = c.dyp, c.lddy
                         c.coef = torch.empty(4 * c.cout, **f32)
                         c.part = torch.empty(max(nblk, lib.yh_bn_bwd_blocks(M, c.cout)) * 2 * c.cout, **f32)
 
@@ -455,8 +573,10 @@ class Plan:
                         alloc_out(r.pair, nblk)
                         q = r.pair
                         # on the main lane whatever lane the record was traced on: both siblings' BN passes depend on it
-                        fwd.append(_op(L.OP_CONV_PW_FWD2, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part, q.bias, q.y, q.part],
-                                       i=[r.x.ld, r.ldwf, r.cout, r.x.B, r.x.H, r.x.W, r.cin, r.cout, q.cout, q.cout], lane=0))
+                        fwd.append(_op(L.OP_CONV_PW_FWD2, p=[r.x.ptr(), r.wf, r.bias, r.yp, r.part, q.bias, q.yp, q.part],
+                                       i=[r.x.ld, r.ldwf, r.ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, q.ldy, q.cout], lane=0))
+                        if r.x_fused:
+                            _set_prologue(fwd[-1], r.x)
                         if deferred_fork:
                             fwd.append(_op(L.OP_FORK))
                             deferred_fork = False
@@ -468,7 +588,7 @@ class Plan:
                         lib.yh_conv_pw_blocks(M, r.cin, r.cout) if r.pw_f else \
                         lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
                     alloc_out(r, nblk)
-                    ytarget, ldy = (r.y, r.cout) if r.bn is not None else (None, r.out.ld)
+                    ytarget, ldy = (r.yp, r.ldy) if r.bn is not None else (None, r.out.ld)
                     if r.narrow_f:
                         fwd.append(_op(L.OP_CONV_NARROW,
                                        p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
@@ -479,6 +599,8 @@ class Plan:
                                        p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                           r.part if r.bn is not None else None],
                                        i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
+                    if r.x_fused:                             # the input's BatchNorm + SiLU is applied while this kernel stages it
+                        _set_prologue(fwd[-1], r.x)
                 nblk = r.nblk
                 if r.bn is not None:
                     track = r.bn.track_running_stats and r.bn.running_mean is not None
@@ -486,12 +608,16 @@ class Plan:
                     fwd.append(_op(L.OP_BN_FINALIZE,
                                    p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
                                       r.bn.running_var if track else None, r.coef,
-                                      r.bn.num_batches_tracked if track else None],
+                                      r.bn.num_batches_tracked if track else None,
+                                      r.out.icoef_ptr(0) if r.virtual else None, r.out.icoef_ptr(1) if r.virtual else None],
                                    i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M], lane=ln))
-                    fwd.append(_op(L.OP_BN_SILU_FWD,
-                                   p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
-                                   i=[r.cout, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
-                                      int(r.upsample)], l=[M], lane=ln))
+                    if not r.virtual:
+                        rf = self._res_fused(r)               # the residual is a raw conv output: normalised on the fly
+                        fwd.append(_op(L.OP_BN_SILU_FWD,
+                                       p=[r.yp, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr(),
+                                          r.residual.icoef_ptr() if rf else None],
+                                       i=[r.ldy, r.residual.ld if r.residual else 0, r.out.ld, r.cout, r.Ho, r.Wo,
+                                          int(r.upsample), r.residual.icoef_ld if rf else 0], l=[M], lane=ln))
             else:
                 if r.fused:
                     continue
@@ -784,21 +910,21 @@ class Plan:
             M = r.x.B * r.Ho * r.Wo
             if r.bn is not None:
                 nb = lib.yh_bn_bwd_blocks(M, r.cout)
-                ops.append(_op(L.OP_BN_SILU_BWD_REDUCE, p=[r.out.gptr(), r.y, r.coef, r.part],
-                               i=[r.out.ld, r.cout, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                ops.append(_op(L.OP_BN_SILU_BWD_REDUCE, p=[r.out.gptr(), r.yp, r.coef, r.part],
+                               i=[r.out.ld, r.ldy, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
                 if r.residual is not None:
                     dres, racc = self._grad_target(r.residual)
                     ldres = r.residual.ld
                 else:
                     dres, racc, ldres = None, 0, 0
                 ops.append(_op(L.OP_BN_SILU_BWD_APPLY,
-                               p=[r.out.gptr(), r.y, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)],
-                                  grad_of[id(r.bn.bias)], r.y, dres],
-                               i=[r.out.ld, r.cout, nb, r.cout, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
+                               p=[r.out.gptr(), r.yp, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)],
+                                  grad_of[id(r.bn.bias)], r.dyp, dres],
+                               i=[r.out.ld, r.ldy, nb, r.lddy, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
                 bn_ops[id(r)] = (r, len(ops) - 2, len(ops) - 1)
                 if r.residual is not None:
                     writers.append((len(ops) - 1, r.residual, None))
-                dy, lddy = r.y.data_ptr(), r.cout
+                dy, lddy = r.dyp, r.lddy
                 self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
             else:
                 dy, lddy = r.out.gptr(), r.out.ld
@@ -811,6 +937,8 @@ class Plan:
                            p=[r.x.ptr(), dy, grad_of[id(r.weight)], self.ws, grad_of[id(r.bias)] if fuse_bias else None],
                            i=[r.x.ld, lddy, r.x.B, r.x.H, r.x.W, r.cin, r.weight.shape[1], r.cout, r.k, r.s],
                            l=[self.ws.numel()]))
+            if r.x_fused:                                          # x is a raw conv output: the kernel normalises it while staging
+                _set_prologue(ops[-1], r.x)
             self.grad_ready[id(r.weight)] = len(ops)
             if fuse_bias:
                 self.grad_ready[id(r.bias)] = len(ops)
@@ -975,6 +1103,12 @@ def _op(kind: int, p=(), i=(), f=(), l=(), lane: int = 0) -> L.YhOp:
     for n, v in enumerate(l):
         o.l[n] = int(v)
     return o
+
+
+def _set_prologue(o: L.YhOp, x: "View"):
+    """Convolution records carry the input-prologue table of their x operand in p[10] and its row stride in i[17]."""
+    o.p[10] = x.icoef_ptr()
+    o.i[17] = x.icoef_ld
 
 
 def _pack(ops: List[L.YhOp]):
