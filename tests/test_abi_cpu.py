@@ -171,3 +171,25 @@ def test_contexts_are_independent_handles():
     assert L.context_for(0) is L.context_for(0) and L.context_for(0) is not L.context_for(1)
     a.close(); b.close()
     assert a.handle is None
+
+
+def test_replacing_a_parameter_or_buffer_bumps_the_generation():
+    """plans / captured hipGraphs bake raw addresses in; re-assigning a Parameter or buffer attribute (also through
+    load_state_dict(assign=True) on a plain nn.Module parent) must be visible to the cheap per-image state token."""
+    import torch
+    from yolo_from_scratch_amd import graph as G
+    y = __import__("yolo_from_scratch_amd")
+    m = y.ConvBlock(4, 8, 3, 1, 1)
+    g0 = G.PARAM_GENERATION[0]
+    m.conv.weight = torch.nn.Parameter(torch.zeros_like(m.conv.weight))
+    assert G.PARAM_GENERATION[0] == g0 + 1
+    m.bn.running_mean = torch.ones(8)
+    assert G.PARAM_GENERATION[0] == g0 + 2
+    parent = torch.nn.Sequential(m)
+    sd = {k: v.clone() for k, v in parent.state_dict().items()}
+    g1 = G.PARAM_GENERATION[0]
+    parent.load_state_dict(sd, assign=True)
+    assert G.PARAM_GENERATION[0] > g1
+    g2 = G.PARAM_GENERATION[0]
+    torch.nn.Linear(3, 3)                      # constructing modules (first registration) does not count
+    assert G.PARAM_GENERATION[0] == g2

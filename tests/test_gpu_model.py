@@ -302,10 +302,14 @@ def test_cpu_tensor_is_rejected_loudly():
         m(torch.zeros(1, 4, 8, 8))
 
 
-@pytest.mark.parametrize("nc,S,B", [(80, 320, 2), (80, 1280, 1)])
+@pytest.mark.parametrize("nc,S,B", [(80, 320, 2), (80, 1280, 1), (1, 640, 64), (80, 640, 64), (80, 1280, 16)])
 def test_other_baseline_configs_match_oracle(nc, S, B):
     """BASELINE configs 3/4 at reduced batch: nc=80 heads (255 output channels, scalar-dy kernels) and a
-    1280x1280 input, where the loss keeps decoding with img_size=640 (reference quirk Q1)."""
+    1280x1280 input, where the loss keeps decoding with img_size=640 (reference quirk Q1) -- and the three configurations
+    BASELINE.json names AT THEIR OWN SIZE (nc=1 640 bs=64; nc=80 640 bs=64; nc=80 1280 bs=16) against the pinned CPU oracle
+    (train.py:888-926): one fused step, loss terms 1e-4, clipped global gradient norm 3e-4, full gradient tensors of five layers
+    3e-3 of their maximum.  The oracle's forward + backward takes a few seconds per case on the box's host cores; these are the
+    only places the large-grid kernel variants that batch 64 selects meet the reference arithmetic."""
     y = api()
     torch.manual_seed(0)
     m = y.YOLO(num_classes=nc, img_size=S)
@@ -464,7 +468,8 @@ def test_long_run_stays_finite_and_learns():
 
 
 def test_full_size_step_properties(monkeypatch):
-    """BASELINE configs[1] size (bs=64, 640x640, nc=1), where the CPU oracle would take minutes: (i) the step is bitwise
+    """BASELINE configs[1] size (bs=64, 640x640, nc=1); parity with the oracle at this size is test_other_baseline_configs_match_oracle
+    [1-640-64]; here: (i) the step is bitwise
     reproducible (every reduction has a fixed order, also in the large-grid kernel variants only this size selects);
     (ii) the specialised kernels (Winograd, pointwise, stem, merged stride-2) and the generic gather-GEMM / wgrad kernels
     are two independent product paths and agree: same loss to 1e-5, gradients to 5e-3 of each tensor's max (two fp32

@@ -20,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from provenance import stamp
 
-FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "bf16_gemm_kernel",
+FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "wino_lds_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "bf16_gemm_kernel",
             "bf16_fstream_kernel", "narrow_conv_kernel", "narrow_first_bf16_kernel", "narrow_s2_16x32_bf16_kernel")
 DGRAD_ONLY = ("narrow_dgrad_s2_kernel", "narrow_dgrad_s2_bf16_kernel")
 WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "wino_wgrad_lds_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "bf16_wgrad_stream_kernel", "wgrad_reduce")

@@ -31,6 +31,23 @@ WEIGHTS_EPOCH = [0]
 PARAM_GENERATION = [0]
 
 
+def _on_reregistration(module, name, value):
+    """Global torch hook: a parameter or buffer attribute that already held a tensor is being REPLACED (`conv.weight =
+    nn.Parameter(...)`, `bn.running_mean = t`, load_state_dict(assign=True) through any parent module).  Plans and captured
+    hipGraphs hold the old tensor's address: bump the generation so every holder re-validates (the per-image check of
+    InferenceSession compares this counter instead of walking the module tree)."""
+    for store in ("_parameters", "_buffers"):
+        d = module.__dict__.get(store)
+        if d is not None and d.get(name) is not None and d.get(name) is not value:
+            PARAM_GENERATION[0] += 1
+            return None
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_on_reregistration)
+torch.nn.modules.module.register_module_buffer_registration_hook(_on_reregistration)
+
+
 def invalidate_folded_weights():
     """Tell every eval plan / InferenceSession that parameter or BatchNorm-buffer VALUES changed behind torch's version
     counters.  The package calls this itself wherever its own code writes parameter storage (optimizer kernels, training
