@@ -284,7 +284,7 @@ int yh_bn_finalize(const float *partials, int nblk, int64_t count, const float *
  * neither): when the activation of this layer is never materialised, the kernels that read it apply it (yh_conv_*_act). */
 int yh_bn_finalize_x(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, float momentum, float eps, float *coef, int C, int64_t *num_batches_tracked, float *xscale,
-                     float *xshift, void *stream);
+                     float *xshift, int64_t *bwd_acc, void *stream);      /* bwd_acc (or NULL): [2][C] accumulators of the backward, zeroed here */
 /* Inference coefficients from running statistics (BN folded to scale/shift). */
 int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
                     float eps, float *coef, int C, void *stream);
@@ -302,6 +302,20 @@ int yh_bn_silu_fwd_res(const float *y, int ldy, const float *coef, const float *
  * da is read with a 2x2 sum when `upsample`.  partials: [nblk][2][C], nblk = yh_bn_bwd_blocks(M). */
 int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef, float *partials,
                           int64_t M, int C, int H, int W, int upsample, void *stream);
+/* The same two passes WITHOUT the finalize launch between them (round 4): the reduce adds every workgroup's channel sums into
+ * acc[2][C] -- 64-bit fixed-point accumulators (2^-36 units; integer atomics, so the totals are bitwise reproducible in any
+ * arrival order), which must be ZERO on entry (yh_bn_finalize_x zeroes them in the forward pass of the same step); the apply
+ * converts the totals once per workgroup and workgroup 0 writes dgamma / dbeta. */
+int yh_bn_silu_bwd_reduce_acc(const float *da, int ldda, const float *y, int ldy, const float *coef, int64_t *acc, int64_t M, int C, int H,
+                              int W, int upsample, void *stream);
+int yh_bn_silu_bwd_apply_acc(const float *da, int ldda, const float *y, int ldy, const float *coef, const int64_t *acc, float *dgamma,
+                             float *dbeta, float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C, int H, int W,
+                             int upsample, void *stream);
+int yh_bf16_bn_silu_bwd_reduce_acc(const void *da, int ldda, const void *y, int ldy, const float *coef, int64_t *acc, int64_t M, int C,
+                                   int H, int W, int upsample, void *stream);
+int yh_bf16_bn_silu_bwd_apply_acc(const void *da, int ldda, const void *y, int ldy, const float *coef, const int64_t *acc, float *dgamma,
+                                  float *dbeta, void *dy, int lddy, void *dres, int lddres, int res_accumulate, int64_t M, int C, int H,
+                                  int W, int upsample, void *stream);
 int yh_bn_bwd_blocks(int64_t M, int C);
 /* Backward stage 2: dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta written from the
  * partials; if dres != NULL the incoming da is also routed to the residual branch

@@ -107,7 +107,11 @@ _SIGS = {
     "yh_colsum": (i32, [c_fp, i32, i64, i32, c_fp, c_fp, c_fp]),
     "yh_colsum_ws": (i64, [i64, i32]),
     "yh_bn_finalize": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp, c_fp]),
-    "yh_bn_finalize_x": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp, c_fp, c_fp, c_fp]),
+    "yh_bn_finalize_x": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "yh_bn_silu_bwd_reduce_acc": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_bn_silu_bwd_reduce_acc": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bn_silu_bwd_apply_acc": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i64, i32, i32, i32, i32, c_fp]),
+    "yh_bf16_bn_silu_bwd_apply_acc": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i64, i32, i32, i32, i32, c_fp]),
     "yh_bn_silu_fwd_res": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "yh_bn_eval_coef": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),
     "yh_bn_silu_fwd": (i32, [c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),

@@ -50,17 +50,24 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_BN_FINALIZE:        /* p[7], p[8]: scale / shift rows of a consumer-side prologue table, or NULL */
             return yh_bn_finalize_x((const float *)p[0], i[0], o.l[0], (const float *)p[1], (const float *)p[2],
                                     (float *)p[3], (float *)p[4], f[0], f[1], (float *)p[5], i[1], (int64_t *)p[6], (float *)p[7],
-                                    (float *)p[8], st);
+                                    (float *)p[8], (int64_t *)p[9], st);          /* p[9]: the layer's backward accumulators, zeroed here */
         case YH_OP_BN_EVAL_COEF:
             return yh_bn_eval_coef((const float *)p[0], (const float *)p[1], (const float *)p[2], (const float *)p[3], f[0],
                                    (float *)p[4], i[0], st);
         case YH_OP_BN_SILU_FWD:        /* p[4] / i[7]: prologue table of a residual that was never materialised, or NULL */
             return yh_bn_silu_fwd_res((const float *)p[0], i[0], (const float *)p[1], (const float *)p[2], i[1], (const float *)p[4], i[7],
                                       (float *)p[3], i[2], o.l[0], i[3], i[4], i[5], i[6], st);
-        case YH_OP_BN_SILU_BWD_REDUCE:
+        case YH_OP_BN_SILU_BWD_REDUCE:     /* p[9] != NULL: fixed-point accumulators instead of partial rows (no finalize launch) */
+            if (p[9])
+                return yh_bn_silu_bwd_reduce_acc((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (int64_t *)p[9],
+                                                 o.l[0], i[2], i[3], i[4], i[5], st);
             return yh_bn_silu_bwd_reduce((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
                                          (float *)p[3], o.l[0], i[2], i[3], i[4], i[5], st);
         case YH_OP_BN_SILU_BWD_APPLY:
+            if (p[9])
+                return yh_bn_silu_bwd_apply_acc((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (const int64_t *)p[9],
+                                                (float *)p[5], (float *)p[6], (float *)p[7], i[3], (float *)p[8], i[4], i[5], o.l[0], i[6],
+                                                i[7], i[8], i[9], st);
             return yh_bn_silu_bwd_apply((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
                                         (const float *)p[3], i[2], (const float *)p[4], (float *)p[5], (float *)p[6],
                                         (float *)p[7], i[3], (float *)p[8], i[4], i[5], o.l[0], i[6], i[7], i[8], i[9], st);
@@ -158,9 +165,15 @@ static int run_one(const yh_op &o, void *st) {
         case YH_OP_BF16_BN_SILU_FWD:
             return yh_bf16_bn_silu_fwd(p[0], i[0], (const float *)p[1], p[2], i[1], p[3], i[2], o.l[0], i[3], i[4], i[5], i[6], st);
         case YH_OP_BF16_BN_SILU_BWD_REDUCE:
+            if (p[9])
+                return yh_bf16_bn_silu_bwd_reduce_acc(p[0], i[0], p[1], i[1], (const float *)p[2], (int64_t *)p[9], o.l[0], i[2], i[3], i[4],
+                                                      i[5], st);
             return yh_bf16_bn_silu_bwd_reduce(p[0], i[0], p[1], i[1], (const float *)p[2], (float *)p[3], o.l[0], i[2], i[3], i[4],
                                               i[5], st);
         case YH_OP_BF16_BN_SILU_BWD_APPLY:
+            if (p[9])
+                return yh_bf16_bn_silu_bwd_apply_acc(p[0], i[0], p[1], i[1], (const float *)p[2], (const int64_t *)p[9], (float *)p[5],
+                                                     (float *)p[6], p[7], i[3], p[8], i[4], i[5], o.l[0], i[6], i[7], i[8], i[9], st);
             return yh_bf16_bn_silu_bwd_apply(p[0], i[0], p[1], i[1], (const float *)p[2], (const float *)p[3], i[2],
                                              (const float *)p[4], (float *)p[5], (float *)p[6], p[7], i[3], p[8], i[4], i[5], o.l[0],
                                              i[6], i[7], i[8], i[9], st);

@@ -383,21 +383,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
             csc0 = ps[0]; csc1 = ps[1]; csh0 = ph[0]; csh1 = ph[1]; cg0 = pg[0]; cg1 = pg[1];
         }
     };
+    // the activation of the parked pieces, in place in the staging registers (padding is zero AFTER the activation)
+    auto stage_math1 = [&](f32x4 (&sr)[NP], int i) {               // element i of the NP x 4 staged values
+        const int k = i >> 2, e = i & 3;
+        float v = sr[k][e];
+        // (pure arithmetic is not ordered against sched_barrier by the instruction selector: the empty volatile asm statements tie
+        // the slice to its place in the instruction stream, between two MFMAs)
+        asm volatile("" : "+v"(v));
+        if constexpr (ACT) v = yh_prologue(v, qq ? csc1[e] : csc0[e], qq ? csh1[e] : csh0[e], qq ? cg1[e] : cg0[e]);
+        v = gofs[k] < 0 ? 0.f : v;
+        asm volatile("" : "+v"(v));
+        sr[k][e] = v;
+    };
+    auto stage_math = [&](f32x4 (&sr)[NP]) {
+#pragma unroll
+        for (int i = 0; i < 4 * NP; ++i) stage_math1(sr, i);
+    };
     auto stage_store = [&](float *buf, const f32x4 (&sr)[NP]) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            f32x4 v = sr[k];
-            if constexpr (ACT) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = yh_prologue(v[e], qq ? csc1[e] : csc0[e], qq ? csh1[e] : csh0[e], qq ? cg1[e] : cg0[e]);
-                }
-            }
-            if (gofs[k] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};        // padding is zero AFTER the activation
 #if defined(YH_WL_ABL) && (YH_WL_ABL & 4)
-            asm volatile("" :: "v"(v));
+            asm volatile("" :: "v"(sr[k]));
 #else
-            if (gofs[k] != -2) *(f32x4 *)(buf + ldst[k]) = v;
+            if (gofs[k] != -2) *(f32x4 *)(buf + ldst[k]) = sr[k];
 #endif
         }
     };
@@ -443,7 +451,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
         coef_load(c1);
         __builtin_amdgcn_sched_barrier(0);
         group(0, c1);
-        group(1, c1);
+        {   // group 1 with the activation of the next chunk's pieces issued BETWEEN its MFMAs (a slice of the ~100 vector instructions
+            // behind each one, order pinned): in one lump ahead of the store they left the matrix pipe idle once per chunk
+            constexpr int NM = 4 * NT, NE = 4 * NP;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int e = i / NT, j = i - e * NT;
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1][e], u[1][j][e], acc[1][j], 0, 0, 0);
+#pragma unroll
+                for (int q = i * NE / NM; q < (i + 1) * NE / NM; ++q) stage_math1(sNext, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if !(defined(YH_WL_ABL) && (YH_WL_ABL & 16))
+#pragma unroll
+            for (int j = 0; j < NT; ++j) u[1][j] = *(const f32x4 *)(ub[j] + upos + c1 * uchunk);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (c < last) stage_store(nxt, sNext);                     // wave-uniform branch around LDS stores only
 #if !(defined(YH_WL_ABL) && (YH_WL_ABL & 1))
         __syncthreads();                                           // chunk c + 1 is parked; chunk c - 1's buffer is free again
@@ -467,6 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
     for (int v = 0; v < 4; ++v)
 #pragma unroll
         for (int j = 0; j < NT; ++j) u[v][j] = *(const f32x4 *)(ub[j] + v * upos);
+    stage_math(sA);
     stage_store(smem, sA);
     stage_load(last > 0 ? 1 : 0, sA);
     __syncthreads();

@@ -246,7 +246,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, dou
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ rmean, float *__restrict__ rvar, float momentum, float eps,
                                    float *__restrict__ coef, int C, int64_t *__restrict__ nbt,
-                                   float *__restrict__ xscale, float *__restrict__ xshift) {
+                                   float *__restrict__ xscale, float *__restrict__ xshift, long long *__restrict__ zacc) {
     __shared__ double rs[16], rq[16];
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
@@ -274,6 +274,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int nblk, dou
             xscale[c] = scale;
             xshift[c] = beta[c] - (float)mean * scale;
         }
+        if (zacc) zacc[c] = zacc[C + c] = 0;      // this layer's BatchNorm-backward accumulators (yh_bn_silu_bwd_reduce_acc), once per step
         if (rmean) {
             double unb = count > 1.0 ? var * count / (count - 1.0) : var;
             rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
@@ -414,7 +415,8 @@ __device__ __forceinline__ typename VecOf<G>::type load_da(const T *__restrict__
 template <typename T, int G>
 __global__ void bn_silu_bwd_reduce_kernel(const T *__restrict__ da, int ldda, const T *__restrict__ y,
                                           int ldy, const float *__restrict__ coef, float *__restrict__ part,
-                                          int64_t M, int C, int H, int W, int upsample, int64_t rows_per_blk) {
+                                          int64_t M, int C, int H, int W, int upsample, int64_t rows_per_blk,
+                                          unsigned long long *__restrict__ acc) {
     typedef typename VecOf<G>::type V;
     extern __shared__ float red[];   // [256][2 G]
     const int t = threadIdx.x, cq = C / G;
@@ -467,7 +469,15 @@ __global__ void bn_silu_bwd_reduce_kernel(const T *__restrict__ da, int ldda, co
         float a = 0.f;
         for (int k = 0; k < rg; ++k) a += red[k * ncol + col];
         const int c4o = col / (2 * G), e = col - c4o * 2 * G;
-        part[((size_t)blockIdx.x * 2 + (e >= G ? 1 : 0)) * C + c4o * G + (e >= G ? e - G : e)] = a;
+        if (acc) {
+            // Totals without a finalize launch: the workgroup's sum goes into a 64-bit FIXED-POINT accumulator (2^-36 units) with an
+            // integer atomic -- integer addition is associative, so the total is bitwise reproducible whatever order the workgroups
+            // arrive in (a float atomic would not be).  Resolution 1.5e-11 per workgroup, range +-1.3e8.
+            const long long q = __double2ll_rn((double)a * 68719476736.0);
+            atomicAdd(acc + (e >= G ? C : 0) + c4o * G + (e >= G ? e - G : e), (unsigned long long)q);
+        } else {
+            part[((size_t)blockIdx.x * 2 + (e >= G ? 1 : 0)) * C + c4o * G + (e >= G ? e - G : e)] = a;
+        }
     }
 }
 
@@ -499,10 +509,22 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const T *__restr
                                          int ldy, const float *__restrict__ coef, const float *__restrict__ dgamma,
                                          const float *__restrict__ dbeta, T *__restrict__ dy, int lddy,
                                          T *__restrict__ dres, int lddres, int res_acc, int64_t M, int C, int H,
-                                         int W, int upsample) {
+                                         int W, int upsample, const long long *__restrict__ acc, float *__restrict__ dgo,
+                                         float *__restrict__ dbo) {
     typedef typename VecOf<G>::type V;
     const int cq = C / G;
     const float inv_n = 1.0f / (float)M;
+    // accumulator mode (acc != null): the totals of yh_bn_silu_bwd_reduce_acc are turned into floats once per workgroup (LDS);
+    // workgroup 0 also writes them out as the parameter gradients
+    extern __shared__ __attribute__((aligned(16))) float tot[];        // [2][C]: dbeta | dgamma
+    if (acc) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            const float v = (float)((double)acc[i] * (1.0 / 68719476736.0));
+            tot[i] = v;
+            if (blockIdx.x == 0) (i < C ? dbo[i] : dgo[i - C]) = v;
+        }
+        __syncthreads();
+    }
     const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     int64_t m = i0 / cq;                       // division-free cursor, see bn_silu_fwd_kernel
     int c4 = (int)(i0 - m * cq);
@@ -513,7 +535,9 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const T *__restr
         mu = *(const V *)(coef + 2 * C + c); is = *(const V *)(coef + 3 * C + c);
 #pragma unroll
         for (int h = 0; h < G; h += 4) {       // (views of the flat gradient buffer: 16-byte aligned only)
-            const f32x4 g4 = *(const f32x4 *)(dgamma + c + h), b4 = *(const f32x4 *)(dbeta + c + h);
+            f32x4 g4, b4;
+            if (acc) { g4 = *(const f32x4 *)(tot + C + c + h); b4 = *(const f32x4 *)(tot + c + h); }     // LDS (never a flat load)
+            else { g4 = *(const f32x4 *)(dgamma + c + h); b4 = *(const f32x4 *)(dbeta + c + h); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { dg[h + e] = g4[e]; db[h + e] = b4[e]; }
         }
@@ -774,10 +798,10 @@ extern "C" int yh_bf16_colsum(const void *x, int ldx, int64_t M, int C, float *o
 
 extern "C" int yh_bn_finalize_x(const float *partials, int nblk, int64_t count, const float *gamma, const float *beta,
                                 float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
-                                int64_t *num_batches_tracked, float *xscale, float *xshift, void *stream) {
+                                int64_t *num_batches_tracked, float *xscale, float *xshift, int64_t *bwd_acc, void *stream) {
     YH_REQUIRE(partials && gamma && beta && coef && nblk > 0 && count > 0 && C > 0 && !xscale == !xshift, "bn_finalize: bad argument");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, (double)count,
-                       gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked, xscale, xshift);
+                       gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked, xscale, xshift, (long long *)bwd_acc);
     YH_CHECK_LAUNCH("bn_finalize");
     return 0;
 }
@@ -785,7 +809,7 @@ extern "C" int yh_bn_finalize(const float *partials, int nblk, int64_t count, co
                               float *running_mean, float *running_var, float momentum, float eps, float *coef, int C,
                               int64_t *num_batches_tracked, void *stream) {
     return yh_bn_finalize_x(partials, nblk, count, gamma, beta, running_mean, running_var, momentum, eps, coef, C, num_batches_tracked,
-                            nullptr, nullptr, stream);
+                            nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int yh_bn_eval_coef(const float *gamma, const float *beta, const float *running_mean,
@@ -852,9 +876,9 @@ extern "C" int yh_bn_bwd_blocks(int64_t M, int C) {
 }
 
 template <typename T>
-static int bn_silu_bwd_reduce_t(const T *da, int ldda, const T *y, int ldy, const float *coef, float *partials, int64_t M, int C,
+static int bn_silu_bwd_reduce_t(const T *da, int ldda, const T *y, int ldy, const float *coef, float *partials, int64_t *acc, int64_t M, int C,
                                 int H, int W, int upsample, void *stream) {
-    YH_REQUIRE(da && y && coef && partials && M > 0 && M < (1ll << 31), "bn_silu_bwd_reduce: bad argument");
+    YH_REQUIRE(da && y && coef && (partials || acc) && M > 0 && M < (1ll << 31), "bn_silu_bwd_reduce: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_reduce", C, ldda, ldy);
     YH_REQUIRE(C <= 1024, "bn_silu_bwd_reduce: C too large");
     int nblk = yh_bn_bwd_blocks(M, C);
@@ -864,54 +888,79 @@ static int bn_silu_bwd_reduce_t(const T *da, int ldda, const T *y, int ldy, cons
     // column per thread
     if (sizeof(T) == 2 && wide_groups<T>(C, {ldda, ldy}, {da, y}))
         hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<T, 8>), dim3(nblk), dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream,
-                           da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
+                           da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows, (unsigned long long *)acc);
     else
         hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<T, 4>), dim3(nblk), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows);
+                           da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, rows, (unsigned long long *)acc);
     YH_CHECK_LAUNCH("bn_silu_bwd_reduce");
     return 0;
 }
 extern "C" int yh_bn_silu_bwd_reduce(const float *da, int ldda, const float *y, int ldy, const float *coef,
                                      float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
-    return bn_silu_bwd_reduce_t<float>(da, ldda, y, ldy, coef, partials, M, C, H, W, upsample, stream);
+    return bn_silu_bwd_reduce_t<float>(da, ldda, y, ldy, coef, partials, nullptr, M, C, H, W, upsample, stream);
+}
+extern "C" int yh_bn_silu_bwd_reduce_acc(const float *da, int ldda, const float *y, int ldy, const float *coef, int64_t *acc, int64_t M,
+                                         int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_reduce_t<float>(da, ldda, y, ldy, coef, nullptr, acc, M, C, H, W, upsample, stream);
+}
+extern "C" int yh_bf16_bn_silu_bwd_reduce_acc(const void *da, int ldda, const void *y, int ldy, const float *coef, int64_t *acc, int64_t M,
+                                              int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_reduce_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, nullptr, acc, M, C, H, W, upsample, stream);
 }
 extern "C" int yh_bf16_bn_silu_bwd_reduce(const void *da, int ldda, const void *y, int ldy, const float *coef,
                                           float *partials, int64_t M, int C, int H, int W, int upsample, void *stream) {
-    return bn_silu_bwd_reduce_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, partials, M, C, H, W, upsample, stream);
+    return bn_silu_bwd_reduce_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, partials, nullptr, M, C, H, W, upsample, stream);
 }
 
 template <typename T>
 static int bn_silu_bwd_apply_t(const T *da, int ldda, const T *y, int ldy, const float *coef,
-                               const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
+                               const float *partials, int nblk, const int64_t *acc, const float *gamma, float *dgamma, float *dbeta,
                                T *dy, int lddy, T *dres, int lddres, int res_accumulate, int64_t M, int C,
                                int H, int W, int upsample, void *stream) {
     (void)gamma;
-    YH_REQUIRE(da && y && coef && partials && dgamma && dbeta && dy && M > 0 && M < (1ll << 31) && nblk > 0, "bn_silu_bwd_apply: bad argument");
+    YH_REQUIRE(da && y && coef && (acc || (partials && nblk > 0)) && dgamma && dbeta && dy && M > 0 && M < (1ll << 31), "bn_silu_bwd_apply: bad argument");
     YH_REQ_VEC4("bn_silu_bwd_apply", C, ldda, ldy, lddy, dres ? lddres : 0);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, dgamma, dbeta,
-                       C);
-    YH_CHECK_LAUNCH("bn_bwd_finalize");
+    if (!acc) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, partials, nblk, dgamma,
+                           dbeta, C);
+        YH_CHECK_LAUNCH("bn_bwd_finalize");
+    }
+    const size_t smem = acc ? (size_t)2 * C * sizeof(float) : 0;
     if (wide_groups<T>(C, {ldda, ldy, lddy, dres ? lddres : 0}, {da, y, dy, dres}))
-        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<T, 8>), dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, da, ldda,
-                           y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<T, 8>), dim3(grid_for(M * (C / 8))), dim3(256), smem, (hipStream_t)stream, da, ldda,
+                           y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample, (const long long *)acc,
+                           dgamma, dbeta);
     else
-        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<T, 4>), dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda,
-                           y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample);
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<T, 4>), dim3(grid_for(M * (C / 4))), dim3(256), smem, (hipStream_t)stream, da, ldda,
+                           y, ldy, coef, dgamma, dbeta, dy, lddy, dres, lddres, res_accumulate, M, C, H, W, upsample, (const long long *)acc,
+                           dgamma, dbeta);
     YH_CHECK_LAUNCH("bn_silu_bwd_apply");
     return 0;
+}
+extern "C" int yh_bn_silu_bwd_apply_acc(const float *da, int ldda, const float *y, int ldy, const float *coef, const int64_t *acc,
+                                        float *dgamma, float *dbeta, float *dy, int lddy, float *dres, int lddres, int res_accumulate,
+                                        int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_apply_t<float>(da, ldda, y, ldy, coef, nullptr, 0, acc, nullptr, dgamma, dbeta, dy, lddy, dres, lddres,
+                                      res_accumulate, M, C, H, W, upsample, stream);
+}
+extern "C" int yh_bf16_bn_silu_bwd_apply_acc(const void *da, int ldda, const void *y, int ldy, const float *coef, const int64_t *acc,
+                                             float *dgamma, float *dbeta, void *dy, int lddy, void *dres, int lddres, int res_accumulate,
+                                             int64_t M, int C, int H, int W, int upsample, void *stream) {
+    return bn_silu_bwd_apply_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, nullptr, 0, acc, nullptr, dgamma, dbeta, (bf16 *)dy,
+                                     lddy, (bf16 *)dres, lddres, res_accumulate, M, C, H, W, upsample, stream);
 }
 extern "C" int yh_bn_silu_bwd_apply(const float *da, int ldda, const float *y, int ldy, const float *coef,
                                     const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
                                     float *dy, int lddy, float *dres, int lddres, int res_accumulate, int64_t M, int C,
                                     int H, int W, int upsample, void *stream) {
-    return bn_silu_bwd_apply_t<float>(da, ldda, y, ldy, coef, partials, nblk, gamma, dgamma, dbeta, dy, lddy, dres, lddres,
+    return bn_silu_bwd_apply_t<float>(da, ldda, y, ldy, coef, partials, nblk, nullptr, gamma, dgamma, dbeta, dy, lddy, dres, lddres,
                                       res_accumulate, M, C, H, W, upsample, stream);
 }
 extern "C" int yh_bf16_bn_silu_bwd_apply(const void *da, int ldda, const void *y, int ldy, const float *coef,
                                          const float *partials, int nblk, const float *gamma, float *dgamma, float *dbeta,
                                          void *dy, int lddy, void *dres, int lddres, int res_accumulate, int64_t M, int C,
                                          int H, int W, int upsample, void *stream) {
-    return bn_silu_bwd_apply_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, partials, nblk, gamma, dgamma, dbeta,
+    return bn_silu_bwd_apply_t<bf16>((const bf16 *)da, ldda, (const bf16 *)y, ldy, coef, partials, nblk, nullptr, gamma, dgamma, dbeta,
                                      (bf16 *)dy, lddy, (bf16 *)dres, lddres, res_accumulate, M, C, H, W, upsample, stream);
 }
 
