@@ -15,6 +15,7 @@ import json
 import os
 import sys
 import time
+from datetime import timedelta
 
 import torch
 
@@ -343,6 +344,20 @@ def main():
     FORCE_COLLECTIVES[0] = bool(args.collectives_at_world_1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)          # before anything touches the GPU in this process
+    try:
+        return run(args)
+    except Exception as e:                # a failed collective / timed-out rank: report and exit non-zero (never re-exec)
+        from yolo_from_scratch_amd.training import CollectiveError
+        if isinstance(e, CollectiveError) or "NCCL" in str(e) or "ProcessGroup" in type(e).__name__:
+            print(f"bench.py: rank {os.environ.get('RANK', '0')}: distributed failure: {e}", file=sys.stderr, flush=True)
+            sys.exit(3)
+        raise
+
+
+DIST_TIMEOUT_S = 300
+
+
+def run(args):
 
     import torch.distributed as dist
     import yolo_from_scratch_amd as y
@@ -360,10 +375,12 @@ def main():
             if local >= ndev:
                 raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # a finite collective timeout: a dead rank ends the job (non-zero exit of every rank through the watchdog / through
+            # GradBuckets.wait -> CollectiveError) instead of hanging the other seven forever
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timedelta(seconds=DIST_TIMEOUT_S))
         else:
             local = local % max(ndev, 1)
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=timedelta(seconds=DIST_TIMEOUT_S))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

@@ -127,3 +127,91 @@ def test_dp_mean_of_replica_gradients_matches_oracle_shards():
         assert p.exitcode == 0
     assert all(r[1] < 1e-7 for r in res)
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3]      # both ranks clip the averaged gradient identically
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yolo_from_scratch_amd.training import GradBuckets
+        errs = []
+        for nb in (1, 4, 8):
+            torch.manual_seed(7 * nb + rank)
+            sizes = [9, 400, 31, 64, 2048, 33, 5, 256, 12, 800, 100, 3]
+            spans, off = [], 0
+            for n in sizes:
+                spans.append((off, (n + 3) // 4 * 4))
+                off += (n + 3) // 4 * 4
+            flat = torch.randn(off)
+            local = flat.clone()
+            ready = list(range(10 * len(sizes), 0, -10))
+            gb = GradBuckets(flat, None, n_buckets=nb)
+            segs = gb.plan_segments(spans, ready, 10 * len(sizes) + 5)
+            cover = torch.zeros(off)
+            for end, rng in segs:
+                if rng is not None:
+                    cover[rng[0]:rng[1]] += 1
+                gb.launch(rng)
+            gb.wait(timeout_s=60.0)
+            assert bool((cover == 1).all()) and segs[-1][0] == 10 * len(sizes) + 5
+            assert sum(1 for _, r in segs if r is not None) <= nb
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            errs.append(float((flat - sum(gathered)).abs().max()))
+        q.put((rank, max(errs)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_plans_world4_gloo():
+    """plan_segments with 1, 4 and 8 buckets on a world of FOUR ranks: every gradient element reduced exactly once, never before
+    its gradient is final, at most n_buckets collectives, sums equal to the all-gathered reference."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(err < 1e-5 for _, err in res)
+
+
+def _dead_rank_worker(rank, world, port, q):
+    from datetime import timedelta
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=20))
+    from yolo_from_scratch_amd.training import GradBuckets, CollectiveError
+    def leave():                                       # flush the result queue, then die without any distributed teardown
+        q.close()
+        q.join_thread()
+        os._exit(0)
+    if rank == 1:
+        q.put((rank, "gone"))
+        leave()                                       # dies before the collective: rank 0 must not hang in wait()
+    flat = torch.randn(1024)
+    gb = GradBuckets(flat, None, n_buckets=2)
+    try:
+        for end, rng in gb.plan_segments([(0, 512), (512, 512)], [2, 1], 3):
+            gb.launch(rng)
+        gb.wait(timeout_s=5.0)
+        q.put((rank, "no error"))
+    except CollectiveError as e:
+        q.put((rank, "CollectiveError"))
+    leave()
+
+
+def test_dead_rank_surfaces_as_collective_error():
+    """SURVEY section 5 (RCCL async error -> abort): a rank that disappears must not hang the others in GradBuckets.wait()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dead_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[1] == "gone" and res[0] == "CollectiveError", res

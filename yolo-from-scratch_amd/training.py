@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+from datetime import timedelta
+
 import torch
 import torch.distributed as dist
 
@@ -41,6 +43,10 @@ def check_targets(targets, shapes, device):
                              "(batch, grid, grid, 3, 5 + num_classes of the model / input batch)")
         out.append(t.contiguous())
     return out
+
+
+class CollectiveError(RuntimeError):
+    """A data-parallel collective failed or timed out; the rank must exit (non-zero), not retry."""
 
 
 class GradBuckets:
@@ -83,13 +89,26 @@ class GradBuckets:
 
     def launch(self, rng):
         if self.active and rng is not None:
-            self._works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.pg,
-                                               async_op=True))
+            try:
+                self._works.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=self.pg,
+                                                   async_op=True))
+            except Exception as e:                     # a communicator that is already in an error state refuses new work
+                self._works = []
+                raise CollectiveError(f"gradient all-reduce could not be enqueued: {e}") from e
 
-    def wait(self):
-        for w in self._works:
-            w.wait()
-        self._works = []
+    def wait(self, timeout_s: Optional[float] = None):
+        """Join the outstanding all-reduces.  A failed or timed-out collective (a dead rank, an RCCL asynchronous error) is
+        raised as CollectiveError instead of hanging the surviving ranks in wait() -- SURVEY section 5: RCCL async error -> abort.
+        The caller lets it propagate: the process ends with a non-zero exit code (never a re-exec), the launcher tears the job
+        down.  timeout_s: None = the process group's own timeout (init_process_group(timeout=...))."""
+        works, self._works = self._works, []
+        for w in works:
+            try:
+                ok = w.wait(timedelta(seconds=timeout_s)) if timeout_s is not None else w.wait()
+            except Exception as e:
+                raise CollectiveError(f"gradient all-reduce failed: {e}") from e
+            if ok is False:
+                raise CollectiveError(f"gradient all-reduce did not complete within {timeout_s} s")
 
 
 class HipTrainer:
