@@ -190,6 +190,18 @@ int yh_conv_wino_fwd(const float *x, int ldx, const float *U, int ldu, const flo
                      float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
 int yh_conv_wino_bwd_data(const float *dy, int lddy, const float *Ub, int ldub, float *dx, int lddx, int B, int H,
                           int W, int Cin, int Cout, int accumulate, void *stream);
+/* Latency-oriented fused convolution for layers with FEW PIXELS (batch-1 inference, BASELINE config 5; round 4): conv (k 1|3,
+ * s 1|2) + folded-BatchNorm bias + SiLU (+ residual) (+ x2 upsample) like yh_conv_fwd_fused, with K split over the 4-16 waves of a
+ * workgroup that owns 32 pixels x 32 channels -- operands straight into the MFMA registers, the partial tiles summed through
+ * LDS in wave order: no split-K slabs, fences or tickets (the in-launch split-K of yh_conv_fwd_fused_splitk costs three extra
+ * memory round trips per layer).  wq: k-quad interleaved pack Wq[(k >> 2)][ldw][k & 3], k = tap * Cin + ci, written by
+ * yh_lat_pack_multi from (folded) OIHW weights; Cin % 8 == 0.  replaces: the eval-mode conv forward of predict()
+ * (train.py:253-265, 1140-1141). */
+int yh_conv_lat_ok(int B, int Hi, int Wi, int Cin, int Cout, int k, int s);
+int yh_conv_lat_fwd_fused(const float *x, int ldx, const float *wq, int ldw, const float *bias, const float *res, int ldr, float *y,
+                          int ldy, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int act_silu, int upsample, void *stream);
+/* n packs in one launch; `table` is a DEVICE array of 32-byte records { const float *oihw; float *wq; int32 Cout, Cin, k*k, ldw; }. */
+int yh_lat_pack_multi(const void *table, int n, void *stream);
 /* ---- input prologue (round 4) ----------------------------------------------------------------------------------------------
  * Every forward / weight-gradient entry point below has an `_act` form taking the prologue table of its x operand: icoef =
  * three rows [scale | shift | gate] of Cin floats, icoef_ld floats apart (NULL: the plain entry point).  The kernel reads the
@@ -526,7 +538,9 @@ enum {
     YH_OP_BF16_CONV_NARROW,       /* slots of YH_OP_CONV_NARROW + i[11] = kpad (padded K rows per tap of the bf16 pack) */
     YH_OP_BF16_CONV_NARROW_DGRAD_S2,   /* slots of YH_OP_CONV_BWD_DATA + i[11] = kpad */
     YH_OP_BF16_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
-    YH_OP_SPPF_POOL3                   /* p: x, y1, y2, y3;  i: ldx, ldy, B, H, W, C */
+    YH_OP_SPPF_POOL3,                  /* p: x, y1, y2, y3;  i: ldx, ldy, B, H, W, C */
+    YH_OP_CONV_LAT_FWD_FUSED,          /* slots of YH_OP_CONV_FWD_FUSED (p[1] = the k-quad interleaved pack of yh_lat_pack_multi) */
+    YH_OP_LAT_PACK_MULTI               /* p: descriptor table;  i: n */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

@@ -292,3 +292,18 @@ def test_two_contexts_two_streams():
     torch.cuda.synchronize()
     assert ctx.info()["side_stream"]
     ctx.close()
+
+
+def test_plan_cache_is_bounded_lru():
+    """every plan owns a full set of activation buffers; the per-module cache keeps the three most recently used."""
+    y = api()
+    m = y.ConvBlock(8, 16, 3, 1, 1).cuda().eval()
+    with torch.no_grad():
+        for hw in (8, 10, 12, 14, 16):
+            m(torch.rand(1, 8, hw, hw, device="cuda"))
+    keys = [k[0][2] for k in m._plans]
+    assert keys == [12, 14, 16] and len(m._plans) == m.PLAN_CACHE_MAX
+    with torch.no_grad():
+        m(torch.rand(1, 8, 12, 12, device="cuda"))            # a hit moves the plan to the recent end
+        m(torch.rand(1, 8, 20, 20, device="cuda"))
+    assert [k[0][2] for k in m._plans] == [16, 12, 20]

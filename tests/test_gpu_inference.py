@@ -179,3 +179,27 @@ def test_folded_weights_follow_every_sanctioned_write_and_invalidate_covers_the_
     m.eval()
     o7 = both()
     assert not torch.equal(o6[0], o7[0])
+
+
+def test_session_follows_reassigned_parameters():
+    """op lists and captured hipGraphs hold raw addresses.  Re-assigning a Parameter attribute, or load_state_dict(
+    assign=True) through a plain nn.Module parent, must make the session re-trace by itself -- eager and graph replay."""
+    y = api()
+    torch.manual_seed(5)
+    m = y.YOLO(num_classes=1, img_size=320).cuda().eval()
+    m.initialize_detection_biases(prior=0.3)
+    img = torch.rand(1, 3, 320, 320, generator=torch.Generator().manual_seed(9))
+    for use_graph in (False, True):
+        ses = y.InferenceSession(m, conf_threshold=0.2, iou_threshold=0.4, use_graph=use_graph)
+        base = ses.run(img)
+        w = m.head_p3[0].conv.weight
+        w0 = w.detach().clone()
+        m.head_p3[0].conv.weight = torch.nn.Parameter((w.detach() * 1.7).clone())     # a NEW tensor at a new address
+        moved = ses.run(img)
+        fresh = y.InferenceSession(m, conf_threshold=0.2, iou_threshold=0.4, use_graph=False).run(img)
+        assert moved == fresh and moved != base
+        parent = torch.nn.Sequential(m)
+        sd = {k: v.clone() for k, v in parent.state_dict().items()}
+        sd["0.head_p3.0.conv.weight"] = w0
+        parent.load_state_dict(sd, assign=True)
+        assert ses.run(img) == base

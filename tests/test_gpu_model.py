@@ -252,8 +252,8 @@ def test_eval_mode_forward_and_predict_pipeline(tmp_path):
 
 def test_eval_fast_kernels_match_oracle_and_generic_path(monkeypatch):
     """Eval plans at batch sizes that fill the chip route 3x3 stride-1 layers to the Winograd kernel and 1x1 layers to the
-    pointwise GEMM, both with the folded-BatchNorm + bias + SiLU (+residual, +upsample) epilogue; the rest stays on the
-    gather-GEMM (with in-launch split-K where M is small).  Same results as the CPU oracle's eval forward and as the
+    pointwise GEMM, both with the folded-BatchNorm + bias + SiLU (+residual, +upsample) epilogue; layers with few pixels run the
+    latency-oriented kernel (K split over the waves of a workgroup), the rest stays on the gather-GEMM.  Same results as the CPU oracle's eval forward and as the
     all-generic routing (YH_EVAL_FAST=0); weights are re-folded when they change."""
     from yolo_from_scratch_amd import _lib as L
     y = api()
@@ -280,7 +280,8 @@ def test_eval_fast_kernels_match_oracle_and_generic_path(monkeypatch):
             outs[fast] = [p.clone() for p in m(x.cuda())]
         kinds = [op.kind for op in m._plan_for(x.cuda()).fwd_ops[0][: m._plan_for(x.cuda()).fwd_ops[1]]]
         nw, npw = kinds.count(L.OP_CONV_WINO_FWD_FUSED), kinds.count(L.OP_CONV_PW_FWD_FUSED)
-        assert (nw >= 8 and npw >= 8 and kinds.count(L.OP_CONV_FWD_FUSED) >= 8) if fast == "1" else (nw == 0 and npw == 0)
+        nrest = kinds.count(L.OP_CONV_FWD_FUSED) + kinds.count(L.OP_CONV_LAT_FWD_FUSED)     # gather-GEMM / few-pixel latency kernel
+        assert (nw >= 8 and npw >= 8 and nrest >= 8) if fast == "1" else (nw == 0 and npw == 0 and kinds.count(L.OP_CONV_LAT_FWD_FUSED) == 0)
     for a, b, r in zip(outs["1"], outs["0"], ref):
         scale = float(r.abs().max())
         assert float((a.cpu() - r).abs().max()) < 1e-4 * max(scale, 1.0)

@@ -192,6 +192,11 @@ static int run_one(const yh_op &o, void *st) {
             return yh_conv_fwd_fused_splitk((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2],
                                             (const float *)p[3], i[2], (float *)p[4], i[3], (float *)p[5], o.l[0], i[4], i[5], i[6],
                                             i[7], i[8], i[9], i[10], i[11], i[12], st);
+        case YH_OP_CONV_LAT_FWD_FUSED:      /* slots of YH_OP_CONV_FWD_FUSED */
+            return yh_conv_lat_fwd_fused((const float *)p[0], i[0], (const float *)p[1], i[1], (const float *)p[2], (const float *)p[3], i[2],
+                                         (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], st);
+        case YH_OP_LAT_PACK_MULTI:
+            return yh_lat_pack_multi(p[0], i[0], st);
         default:
             yh_set_error("yh_run: unknown op kind %d", o.kind);
             return YH_E_BADARG;

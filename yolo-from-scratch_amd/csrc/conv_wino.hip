@@ -368,13 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
     // under a branch makes every later counted s_waitcnt a vmcnt(0), which would wait for the prefetches in front of the MFMAs
     auto stage_load = [&](int c, f32x4 (&sr)[NP]) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-#if defined(YH_WL_ABL) && (YH_WL_ABL & 2)
-            sr[k] = f32x4{(float)c, 1.f, 2.f, 3.f};
-#else
-            sr[k] = *(const YH_GLOBAL f32x4 *)(ing + (gofs[k] > 0 ? gofs[k] : 0) + c * KC);
-#endif
-        }
+        for (int k = 0; k < NP; ++k) sr[k] = *(const YH_GLOBAL f32x4 *)(ing + (gofs[k] > 0 ? gofs[k] : 0) + c * KC);
     };
     auto coef_load = [&](int c) {
         if constexpr (ACT) {
@@ -402,11 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
     auto stage_store = [&](float *buf, const f32x4 (&sr)[NP]) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-#if defined(YH_WL_ABL) && (YH_WL_ABL & 4)
-            asm volatile("" :: "v"(sr[k]));
-#else
             if (gofs[k] != -2) *(f32x4 *)(buf + ldst[k]) = sr[k];
-#endif
         }
     };
 
@@ -427,21 +417,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
             for (int j = 0; j < NT; ++j)
                 acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[v][e], u[v][j][e], acc[v][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-#if !(defined(YH_WL_ABL) && (YH_WL_ABL & 16))
 #pragma unroll
         for (int j = 0; j < NT; ++j) u[v][j] = *(const f32x4 *)(ub[j] + v * upos + cn * uchunk);   // next chunk, in place
-#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     auto read_patch = [&](const float *buf) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-#if defined(YH_WL_ABL) && (YH_WL_ABL & 8)
-            d[0][cc] = V[cc] + 1.f; d[1][cc] = V[cc] - 1.f;
-#else
             d[0][cc] = *(const f32x4 *)(buf + rdA[cc & 1] + 4 * (cc >> 1));
             d[1][cc] = *(const f32x4 *)(buf + rdB[cc & 1] + 4 * (cc >> 1));
-#endif
         }
     };
     auto iteration = [&](int c, f32x4 (&sNext)[NP], f32x4 (&sFar)[NP]) {
@@ -462,16 +446,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
                 for (int q = i * NE / NM; q < (i + 1) * NE / NM; ++q) stage_math1(sNext, q);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#if !(defined(YH_WL_ABL) && (YH_WL_ABL & 16))
 #pragma unroll
             for (int j = 0; j < NT; ++j) u[1][j] = *(const f32x4 *)(ub[j] + upos + c1 * uchunk);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c < last) stage_store(nxt, sNext);                     // wave-uniform branch around LDS stores only
-#if !(defined(YH_WL_ABL) && (YH_WL_ABL & 1))
         __syncthreads();                                           // chunk c + 1 is parked; chunk c - 1's buffer is free again
-#endif
         read_patch(nxt);
         __builtin_amdgcn_sched_barrier(0);
         group(2, c1);

@@ -445,6 +445,7 @@ class Plan:
         packs: List[tuple] = []                # one descriptor per conv for the single pack launch
         folds: List[tuple] = []                # inference: BN folded into the packed weights
         winos: List[tuple] = []                # Winograd weight transforms (forward and backward-data)
+        latpacks: List[tuple] = []             # k-quad packs of the latency-oriented inference kernel (conv_lat.hip)
         # YH_GENERIC=1: every convolution on the generic gather-GEMM / wgrad kernels instead of the specialised families
         # (Winograd, pointwise, narrow, merged stride-2): the two are independent product paths that must agree
         # (tests/test_gpu_model.py::test_full_size_step_properties); the only planner switch besides YH_EVAL_FAST
@@ -514,7 +515,19 @@ class Plan:
                         and ((M + 127) // 128) * ((r.cout + 127) // 128) >= 128
                     args = dict(i=[r.x.ld, r.ldwf, r.residual.ld if r.residual else 0, r.out.ld, r.x.B, r.x.H, r.x.W,
                                    r.cin, r.cout, r.k, r.s, int(bn is not None), int(r.upsample)], lane=ln)
-                    if wino_e:
+                    # layers with few pixels (batch-1 inference): K split over the waves of a workgroup, no split-K slabs / fences
+                    # (measured at batch 1, 640x640, end to end / device ms with the uint8 image: off 1.283 / 1.227, M <= 8192 0.955 / 0.842,
+                    # M <= 32768 0.954 / 0.845, every layer 0.924 / 0.842 -- the 160x160 layers are a wash, larger M belongs to the
+                    # throughput kernels)
+                    lat_max = 32768
+                    lat_e = fast and aligned and not wino_e and not pw_e and M <= lat_max and r.cin % 8 == 0 \
+                        and bool(lib.yh_conv_lat_ok(r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s))
+                    if lat_e:
+                        r.wf = torch.zeros(kk * r.cin * r.ldwf, **f32)
+                        latpacks.append((wfold.data_ptr(), r.wf.data_ptr(), r.cout, cin_real, kk, r.ldwf))
+                        fwd.append(_op(L.OP_CONV_LAT_FWD_FUSED,
+                                       p=[r.x.ptr(), r.wf, fbias, r.residual.ptr() if r.residual else None, r.out.ptr()], **args))
+                    elif wino_e:
                         r.wf = torch.empty(16 * r.cin * r.ldwf, **f32)
                         winos.append((wfold.data_ptr(), r.wf.data_ptr(), r.cout, cin_real, r.ldwf, 0))
                         fwd.append(_op(L.OP_CONV_WINO_FWD_FUSED,
@@ -660,6 +673,10 @@ class Plan:
             blob = b"".join(struct.pack("<QQQiiiiii", *d) for d in pwpacks)
             self.pw_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
             head.insert(0, _op(L.OP_PW_PACK_MULTI, p=[self.pw_table], i=[len(pwpacks)]))
+        if latpacks:
+            blob = b"".join(struct.pack("<QQiiii", *d) for d in latpacks)
+            self.lat_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+            head.insert(0, _op(L.OP_LAT_PACK_MULTI, p=[self.lat_table], i=[len(latpacks)]))
         if winos:
             blob = b"".join(struct.pack("<QQiiii", *d) for d in winos)
             self.wino_table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)

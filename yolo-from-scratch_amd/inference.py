@@ -188,19 +188,23 @@ def predict_batch(model, images, device, num_classes=1, conf_threshold=0.5, iou_
 class InferenceSession:
     """bs=1 end-to-end inference (BASELINE config 5): image load (NCHW float -> NHWC, or HWC uint8 -> NHWC with the
     reference's /255), BN-folded fused convs, candidate extraction, global NMS, the result table and its device->host
-    copy, captured ONCE into a hipGraph (via torch.cuda.CUDAGraph on the launch stream) and replayed per image.
-    Everything the graph touches has a fixed address: the input image, the letterbox parameters {pad_left, pad_top,
-    scale}, all outputs and the pinned host mirror of the result table.
+    copy -- enqueued eagerly per image (the lowest end-to-end latency: the device starts on the first kernel while the host
+    enqueues the rest), or with use_graph=True captured ONCE into a hipGraph (torch.cuda.CUDAGraph on the launch stream) and
+    replayed per image (less host time per image, better back-to-back throughput, ~0.08 ms more latency: hipGraphLaunch's
+    host-side work precedes the first node).  Everything has a fixed address either way: the input image, the letterbox
+    parameters {pad_left, pad_top, scale}, all outputs and the pinned host mirror of the result table.
 
-    Per image the host does: one cheap weight-state check, one host->device copy of the image, one graph launch, one
-    stream synchronisation, and reads the kept rows out of pinned memory.
+    Per image the host does: one cheap weight-state check, one host->device copy of the image, the launches (or one graph
+    launch), one stream synchronisation, and reads the kept rows out of pinned memory.
 
     Weight changes: anything done through this package (optimizer steps, training forwards, load_state_dict, .to()) or
     through in-place torch ops on the registered parameters / buffers is picked up automatically.  After writes torch cannot
     see on those tensors (`p.data.mul_()`, `trainer.flat_p` views, in-place collectives) call
-    `model.invalidate_folded_weights()`; after re-assigning a parameter / buffer attribute call `session.refresh()`."""
+    `model.invalidate_folded_weights()`.  Re-assigned parameter / buffer attributes (`conv.weight = nn.Parameter(...)`,
+    load_state_dict(assign=True) through any parent module) are seen through torch's global registration hooks
+    (graph._on_reregistration): the session re-traces and re-captures by itself."""
 
-    def __init__(self, model, conf_threshold=0.5, iou_threshold=0.4, use_graph=True, nms_mode=DEFAULT_NMS_MODE):
+    def __init__(self, model, conf_threshold=0.5, iou_threshold=0.4, use_graph=False, nms_mode=DEFAULT_NMS_MODE):
         self.model = model.eval()
         p0 = next(model.parameters())
         if not p0.is_cuda:
@@ -255,28 +259,13 @@ class InferenceSession:
             self._vsum = v
             self.plan.refresh_folded_weights(_stream(self.device))
 
-    def _split_point(self) -> int:
-        """Index at which the forward op list is cut into the two graphs of a replay: the first lane-joined position nearest
-        to a quarter of the list (about 0.25 ms of kernels -- as long as the host needs to launch the second, larger graph)."""
-        ops, n = self.plan.fwd_ops
-        depth, cands = 0, []
-        for i in range(n):
-            k = ops[i].kind
-            if k == L.OP_FORK:
-                depth = 1
-            elif k == L.OP_JOIN:
-                depth = 0
-            if depth == 0 and ops[i].lane == 0:
-                cands.append(i + 1)
-        cands = [c for c in cands if 0 < c < n]
-        return min(cands, key=lambda c: abs(c - n // 4)) if cands else n
-
     def _capture(self, kind: str):
-        """TWO graphs per input kind: a short head (image load + the first quarter of the forward) and the rest.  hipGraphLaunch
-        does its host-side work before the first node starts; the head launches in a fraction of the time of one 75-node graph
-        and the device works through it while the host launches the tail.  Measured: end to end 1.41 -> 1.36 ms with the fp32
-        host image (eager launches: 1.33); what is left is the graph's own per-node cost on the device (the same kernels span
-        1.20 ms as graph nodes, 1.11 ms as stream launches)."""
+        """ONE hipGraph per input kind (image load + forward + post-process).  What a replay buys is HOST time per image (one
+        launch call instead of ~75) and back-to-back throughput; its end-to-end latency is hipGraphLaunch's host-side work
+        (which precedes the first node) above the eager path's, where the device starts on the first kernel while the host is
+        still enqueueing the rest: profiles/r03_infer_latency.json 1.422 / 1.354 ms replayed against 1.340 / 1.274 ms eager
+        (fp32 / uint8 image).  Round 3 split the replay into a short head graph and a tail graph to hide that prelude; the
+        stored records do not show a gain, so the split is gone and `use_graph` defaults to False."""
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -284,30 +273,18 @@ class InferenceSession:
                 self._enqueue(kind)            # warm-up: kernel attributes, lazy module state
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        cut = self._split_point()
-        head = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(head):
-            self._enqueue(kind, 0, cut)
-        tail = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(tail, pool=head.pool()):
-            self._enqueue(kind, cut, None)
-        self.graphs[kind] = (head, tail)
-        return self.graphs[kind]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._enqueue(kind)
+        self.graphs[kind] = graph
+        return graph
 
-    def _enqueue(self, kind: str, first: int = 0, last=None):
-        """Everything a replay repeats (ops [first, last) of the forward list; the image load goes with first == 0, the
-        post-process with last is None).  BatchNorm folding is NOT in here: it depends on the weights only and runs (eagerly,
-        before the replay) when the weight state changed."""
-        import ctypes as C
+    def _enqueue(self, kind: str):
+        """Everything a replay repeats: image load, forward list, post-process.  BatchNorm folding is NOT in here: it depends on the
+        weights only and runs (eagerly, before the replay) when the weight state changed."""
         ops, n = self.plan.fwd_ops
-        stop = n if last is None else last
-        if first == 0:
-            self.model._load_input(self.plan, self.x if kind == "f32" else self.x_u8)
-        if stop > first:
-            part = (L.YhOp * (stop - first)).from_address(C.addressof(ops) + first * C.sizeof(L.YhOp))
-            L.run_ops(part, stop - first, _stream(self.device), self.plan._ctx())
-        if last is not None:
-            return
+        self.model._load_input(self.plan, self.x if kind == "f32" else self.x_u8)
+        L.run_ops(ops, n, _stream(self.device), self.plan._ctx())
         preds = [v.buf.data.view(1, v.H, v.W, 3, v.C // 3) for v in self.heads]
         self.det.candidates(preds, self.model.anchors, self.S, self.conf, letterbox_dev=self.lb)
         self.det.nms(self.iou, self.nms_mode)
@@ -326,9 +303,7 @@ class InferenceSession:
             self.lb.copy_(torch.tensor(lb, dtype=torch.float32))
             self._lb_host = lb
         if self.use_graph:
-            head, tail = self.graphs.get(kind) or self._capture(kind)
-            head.replay()
-            tail.replay()
+            (self.graphs.get(kind) or self._capture(kind)).replay()
         else:
             self._enqueue(kind)
         return self.det.read() if fetch else None
