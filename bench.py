@@ -118,7 +118,7 @@ def host_cores():
     return n
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def stored_traffic(nc, img, batch, dtype, size):
@@ -135,6 +135,18 @@ def stored_traffic(nc, img, batch, dtype, size):
     return doc["groups"]["fwd_conv"]["hbm_bytes_per_step"], (
         f"HBM-side bytes per step over the forward-convolution launches (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(path)}, "
         f"tools/step_profile.py, stamp {doc['stamp']})")
+
+
+def step_conv_flops(plan):
+    """Algorithmic convolution FLOPs of one training step per image: forward + backward-weight of every convolution, backward-data of
+    every convolution whose input needs a gradient (not the first layer)."""
+    from yolo_from_scratch_amd import graph as G
+    tot = 0
+    for r in plan.recs:
+        if isinstance(r, G.ConvRec):
+            f = 2 * r.weight.shape[1] * r.cout * r.k * r.k * r.Ho * r.Wo
+            tot += 2 * f + (f if r.need_dx else 0)
+    return tot
 
 
 def cpu_baseline(batch=8, steps=3):
@@ -254,9 +266,11 @@ def roofline_f32(model, trainer, imgs, targets, nc, img, batch, size):
             "traffic_note": traffic_note + "; algorithmic 8.41e9 (8 sibling pairs share one launch: 62 convs = 54 launches)",
             "executed_mfma_tflops": round(executed / (conv_ms * 1e-3) / 1e12, 2),
             "executed_mfma_frac": round(executed / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            "kernel": "forward convolutions: wino_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3): executes 4/9 of "
-                      "the algorithmic multiplies) + pw_tile_kernel / pw_stream_kernel (1x1) + gather_gemm_kernel (stride-2, "
-                      "head outputs) + narrow_conv_kernel (16-channel 3x3 layers, stem[3], stem[0])",
+            "kernel": "forward convolutions: wino_lds_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3) with the input patch staged "
+                      "through LDS: executes 4/9 of the algorithmic multiplies) + pw_tile_kernel / pw_stream_kernel (1x1) + "
+                      "gather_gemm_kernel (stride-2, wide 1x1) + narrow_conv_kernel (16-channel 3x3 layers, stem[3], stem[0]); since round 4 "
+                      "most of these kernels also apply their input's BatchNorm + SiLU while staging it (89 % of the normalised elements "
+                      "are never materialised), so their time includes what the separate bn_silu_fwd pass used to cost",
             "narrow_ms_per_step": round(per_kind.get(L.OP_CONV_NARROW, 0.0), 3),
             "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
             "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
@@ -399,6 +413,12 @@ def run(args):
     }
     if rank == 0 and not args.no_roofline:
         roof, by_op = (roofline_bf16 if DTYPE == "bf16" else roofline_f32)(model, trainer, imgs, targets, NC, IMG, BATCH, SIZE)
+        if DTYPE == "f32":
+            # the metric is the whole training step: 3 x the forward-convolution FLOPs minus the first layer's backward-data
+            # (SURVEY 8d), all algorithmic, against the fp32 MFMA peak
+            step_flops = step_conv_flops(model._plan_for(imgs)) * BATCH
+            roof["step_algorithmic_gflop"] = round(step_flops / 1e9, 1)
+            roof["step_frac"] = round(step_flops / (base["ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
         result["roofline"], result["forward_ms_by_op"] = roof, by_op
     if world > 1:
         dist.barrier()
@@ -425,6 +445,9 @@ def run(args):
         if (IMG, SIZE) == (640, "s"):       # BASELINE configs[0]: the reference's own CPU-runnable case, batch 2
             b2 = cpu_baseline(batch=2, steps=5)
             result["cpu_baseline"]["config1_batch2"] = {"value": b2["value"], "unit": b2["unit"], "sample": b2["sample"]}
+            if headline:                    # the metric's own batch ("B=64 if memory/time allow"): ~1.5 s per step on 16 cores
+                b64 = cpu_baseline(batch=BATCH, steps=3)
+                result["cpu_baseline"]["batch64"] = {"value": b64["value"], "unit": b64["unit"], "sample": b64["sample"]}
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()

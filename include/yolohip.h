@@ -409,9 +409,11 @@ int64_t yh_candidates_ws(const int grid[3]);
  *                            per operation), then ONE class-agnostic NMS over the shifted boxes;
  *   YH_NMS_TORCHVISION_CPU   torchvision's own rule for a CPU tensor -- the reference's CPU path, the parity target:
  *                            4 M > 4000 -> per class, else coordinate trick (decided on the device from count[0]);
- *   YH_NMS_TORCHVISION_CUDA  the same rule with torchvision's limit for GPU tensors (20000).
- * iou_thr is a double like the `double iou_threshold` of torchvision's CPU kernel, which promotes the fp32 IoU for the
- * comparison (thr = 0.4 suppresses an IoU of exactly float32(0.4)).  M is read from count[0] on the device (clamped to
+ *   YH_NMS_TORCHVISION_CUDA  what the reference executes when predict() runs on a GPU device: the same rule with torchvision's
+ *                            limit for GPU tensors (20000) AND its device kernel's float-against-float comparison.
+ * Which reference device each mode reproduces: PER_CLASS / COORDINATE_TRICK / TORCHVISION_CPU = torchvision's CPU kernel
+ * (`double iou_threshold`: the fp32 IoU is promoted for the comparison, so thr = 0.4 suppresses an IoU of exactly
+ * float32(0.4)); TORCHVISION_CUDA = the CUDA kernel (`float iou_threshold`: that pair is kept).  M is read from count[0] on the device (clamped to
  * cap).  keep (cap) int32 receives kept candidate indices in descending score order, nkeep[0] their number.
  * ws: >= yh_nms_ws(cap) bytes, 256-byte aligned. */
 #define YH_NMS_PER_CLASS 0

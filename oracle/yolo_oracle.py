@@ -303,11 +303,14 @@ def candidates(preds, anchors_list, img_size: int, num_classes: int, conf_thresh
 NMS_MODES = ("vanilla", "trick", "cpu", "cuda")   # "cpu"/"cuda" = torchvision's size rule for a tensor on that device
 
 
-def nms_plain(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
-    """torchvision.ops.nms, CPU kernel, fp32 boxes: kept indices in descending-score order (ties: lower index first)."""
+def nms_plain(boxes: np.ndarray, scores: np.ndarray, thr: float, float_threshold: bool = False) -> np.ndarray:
+    """torchvision.ops.nms, fp32 boxes: kept indices in descending-score order (ties: lower index first).  The CPU kernel takes
+    the threshold as a C double and promotes the fp32 IoU for the comparison; the CUDA kernel (float_threshold) compares
+    float against float -- an IoU exactly equal to float(thr) is suppressed by the first and kept by the second when
+    float(thr) > thr."""
     boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
     scores = np.asarray(scores, np.float32).reshape(-1)
-    thr = float(thr)                                              # C double in the kernel's signature
+    thr = float(np.float32(thr)) if float_threshold else float(thr)
     order = np.argsort(-scores, kind="stable")
     x1, y1, x2, y2 = (boxes[:, k] for k in range(4))
     with np.errstate(invalid="ignore", over="ignore"):
@@ -354,12 +357,13 @@ def nms_batched(boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray, thr:
     classes = np.asarray(classes).reshape(-1).astype(np.int64)
     if len(scores) == 0:
         return np.zeros(0, np.int64)
+    f32thr = mode == "cuda"                                          # the device kernel's float-vs-float comparison
     if nms_uses_trick(len(scores), mode):
-        return nms_plain(nms_shifted_boxes(boxes, classes), scores, thr)
+        return nms_plain(nms_shifted_boxes(boxes, classes), scores, thr, f32thr)
     keep_mask = np.zeros(len(scores), bool)
     for c in np.unique(classes):
         cur = np.nonzero(classes == c)[0]
-        keep_mask[cur[nms_plain(boxes[cur], scores[cur], thr)]] = True
+        keep_mask[cur[nms_plain(boxes[cur], scores[cur], thr, f32thr)]] = True
     keep = np.nonzero(keep_mask)[0]
     return keep[np.argsort(-scores[keep], kind="stable")].astype(np.int64)          # CPU torch.sort is a stable sort
 

@@ -594,8 +594,9 @@ extern "C" int yh_nms(const float *boxes, const float *scores, const int32_t *cl
     a.boxes = boxes; a.scores = scores; a.classes = classes; a.count = count;
     a.cap = cap; a.W = (cap + 63) / 64; a.keep = keep; a.nkeep = nkeep; a.mode = mode;
     // (double)iou > thr  <=>  iou > (largest float <= thr): the CPU kernel's promoted comparison, done in fp32
+    // mode YH_NMS_TORCHVISION_CUDA reproduces torchvision's DEVICE kernel, which compares float against float
     a.thr = (float)iou_thr;
-    if ((double)a.thr > iou_thr) a.thr = nextafterf(a.thr, -INFINITY);
+    if (mode != YH_NMS_TORCHVISION_CUDA && (double)a.thr > iou_thr) a.thr = nextafterf(a.thr, -INFINITY);
     char *p = (char *)ws;
     a.sboxes = (float *)p;    p += align_up((size_t)cap * 16, 256);
     a.sclasses = (int32_t *)p; p += align_up((size_t)cap * 4, 256);
