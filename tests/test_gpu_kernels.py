@@ -508,3 +508,49 @@ def test_narrow_weight_gradient_kernel(B, H, W, Cin, creal, Cout, s):
     L.check(lib.yh_conv_bwd_weight(*args, dw3.data_ptr(), ws_g.data_ptr(), nws_g, B, H, W, Cin, creal, Cout, 3, s, st), "generic wgrad")
     assert rel_err(dw, dw3) < 1e-5
     assert lib.yh_conv_narrow_bwd_weight(*args, dw2.data_ptr(), None, ws.data_ptr(), nws - 1, B, H, W, Cin, creal, Cout, s, st) != 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,res,up,act", [
+    (1, 20, 20, 256, 256, 3, 1, True, False, True),      # K = 2304: 288 chunks over eight waves
+    (1, 40, 40, 64, 64, 3, 1, False, True, True),        # x2 upsample on write
+    (1, 9, 11, 8, 24, 3, 1, False, False, True),         # ONE chunk per tap, 9 chunks: waves past the end of K, ragged M and N
+    (2, 7, 5, 16, 18, 1, 1, False, False, False),        # two chunks, four waves, head-like N = 18, no activation
+    (1, 13, 10, 24, 255, 1, 1, True, False, True),       # three chunks, N = 255
+    (1, 21, 17, 32, 40, 3, 2, False, False, True),       # stride 2, odd sizes
+    (3, 8, 8, 72, 32, 3, 1, True, True, True),           # 81 chunks, residual + upsample
+])
+def test_latency_inference_conv(B, H, W, Cin, Cout, k, s, res, up, act):
+    """conv_lat.hip (batch-1 inference layers: K split over the waves of a workgroup, no split-K slabs): conv + bias + SiLU
+    (+ residual) (+ x2 upsample) against an fp64 evaluation, through the C ABI; shapes that leave waves without K chunks, rows
+    and columns past the tile, padding on every side."""
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(B * 100 + H + Cin)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    r = torch.randn(B, Cout, Ho, Wo) if res else None
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=s, padding=k // 2)
+    if act:
+        ref = ref * torch.sigmoid(ref)
+    if res:
+        ref = ref + r.double()
+    if up:
+        ref = ref.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    assert lib.yh_conv_lat_ok(B, H, W, Cin, Cout, k, s) == 1
+    xd, wd, bd = nhwc(x), w.cuda(), bias.cuda()
+    ldw = rup4(Cout)
+    wq = torch.full((k * k * Cin * ldw,), float("nan"), device="cuda")       # every element the kernel reads must be written by the pack
+    tab = torch.cat([torch.tensor([wd.data_ptr(), wq.data_ptr()], dtype=torch.int64).view(torch.uint8),
+                     torch.tensor([Cout, Cin, k * k, ldw], dtype=torch.int32).view(torch.uint8)]).cuda()
+    L.check(lib.yh_lat_pack_multi(tab.data_ptr(), 1, st))
+    rd = nhwc(r) if res else None
+    f = 2 if up else 1
+    y = torch.full((B, Ho * f, Wo * f, Cout), float("nan"), device="cuda")
+    L.check(lib.yh_conv_lat_fwd_fused(xd.data_ptr(), Cin, wq.data_ptr(), ldw, bd.data_ptr(), rd.data_ptr() if res else None, Cout,
+                                      y.data_ptr(), Cout, B, H, W, Cin, Cout, k, s, int(act), int(up), st))
+    torch.cuda.synchronize()
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
+    assert lib.yh_conv_lat_ok(B, H, W, Cin + 4, Cout, k, s) == 0                 # Cin % 8 != 0: not this kernel's problem

@@ -7,14 +7,13 @@
 // 1.08 of the 1.24 ms the device spends on an image.
 //
 // Here K is split over the WAVES of one workgroup instead of over workgroups:
-//   * a workgroup owns 32 output pixels x 32 output channels; wave w of NW (4, 8 or 16) owns a contiguous range of 8-channel
+//   * a workgroup owns 32 output pixels x 32 output channels; wave w of NW (4 or 8) owns a contiguous range of 8-channel
 //     K chunks (k = tap * Cin + ci);
 //   * operands go straight into the MFMA operand registers, no LDS and no barrier in the loop (the scheme of the pointwise and
 //     Winograd kernels): lane (r = lane & 31, h = lane >> 5) loads the float4 of channels ci0 + 4h .. + 3 of ITS pixel at the
 //     chunk's tap (A operand of four v_mfma_f32_32x32x2_f32) and the float4 Wq[(k >> 2)][n][0..3] of its column from the
 //     k-quad interleaved weight pack (B operand); padding pixels load a valid address and are zeroed by a select;
-//   * every wave keeps two batches of six chunks in flight: a layer's whole K range is two or three overlapping round trips
-//     deep, whatever K is;
+//   * every wave keeps two batches of LB chunks in flight behind its MFMAs;
 //   * the NW partial 32 x 32 tiles are summed through LDS in wave order (fixed order: bitwise reproducible), then bias, SiLU,
 //     residual, x2 upsample and 128-byte row stores -- no slabs, no fences, no tickets, nothing another workgroup waits for.
 // Same results as yh_conv_fwd_fused to fp32 summation order.  replaces: the eval-mode ConvBlock / Conv2d forward of predict()
@@ -23,7 +22,11 @@
 
 namespace {
 
-constexpr int LB = 6;           // K chunks (8 channels each) per batch and wave
+// K chunks (8 channels each) per batch and wave.  Measured per layer at batch 1 (tools/lat_bench.py, us; waves x LB): 80x80 64->64 3x3
+// 18.5 (8 x 6) / 15.9 (8 x 2) / 14.7 (4 x 3) / 18.8 (16 x 2); 20x20 256->256 3x3 27.8 (16 x 6) / 21.8 (8 x 2); 40x40 256->64 1x1
+// 7.4 (4 x 6) / 5.2 (8 x 2); 80x80 128->32 1x1 6.8 / 4.8 -- short batches keep the register count low (more waves resident) and
+// waste fewer MFMAs on the dead chunks of a ragged last batch; eight waves beat four and sixteen.
+constexpr int LB = 2;
 
 struct LatConv {
     const float *in, *Wq, *bias, *res;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(64 * NW) void lat_conv_kernel(const LatConv g) {
         for (int i = 0; i < LB; ++i) {
             const int c = c0 + i;
             const bool live = c < c_end;
-            const int cc = live ? c : c_begin;
+            const int cc = live ? c : 0;                           // (a wave past the end of K has c_begin >= nchunks: chunk 0 always exists)
             const int tap = cc / cpt, ci = (cc - tap * cpt) << 3;  // wave-uniform
             const int dy = tap / g.k, dx = tap - dy * g.k;
             const bool ok = live && (okm >> tap & 1);
@@ -160,12 +163,8 @@ void lat_magic(unsigned d, unsigned &magic, int &shift) {
     shift = l - 1;
 }
 
-// waves per workgroup: enough that a wave's share of K is at most two batches, at most 16
-int lat_waves(int nchunks) {
-    if (nchunks <= 4 * 2 * LB) return 4;
-    if (nchunks <= 8 * 2 * LB) return 8;
-    return 16;
-}
+// waves per workgroup: eight (measured above), four when K has fewer than eight chunks
+int lat_waves(int nchunks) { return nchunks < 8 ? 4 : 8; }
 
 }  // namespace
 
@@ -207,8 +206,7 @@ extern "C" int yh_conv_lat_fwd_fused(const float *x, int ldx, const float *wq, i
     dim3 grid(cdiv(g.M, 32), cdiv(Cout, 32));
     hipStream_t st = (hipStream_t)stream;
     if (NW == 4) hipLaunchKernelGGL((lat_conv_kernel<4>), grid, dim3(256), 0, st, g);
-    else if (NW == 8) hipLaunchKernelGGL((lat_conv_kernel<8>), grid, dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((lat_conv_kernel<16>), grid, dim3(1024), 0, st, g);
+    else hipLaunchKernelGGL((lat_conv_kernel<8>), grid, dim3(512), 0, st, g);
     YH_CHECK_LAUNCH("conv_lat");
     return 0;
 }
