@@ -202,6 +202,14 @@ int yh_conv_lat_fwd_fused(const float *x, int ldx, const float *wq, int ldw, con
                           int ldy, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, int act_silu, int upsample, void *stream);
 /* n packs in one launch; `table` is a DEVICE array of 32-byte records { const float *oihw; float *wq; int32 Cout, Cin, k*k, ldw; }. */
 int yh_lat_pack_multi(const void *table, int n, void *stream);
+/* 3x3 stride-2 forward with the input patch staged through LDS (round 4: the down-sampling layers with Cin % 8 == 0 and
+ * Cout % 32 == 0; yh_conv_s2_ok).  wq: the k-quad interleaved pack of yh_lat_pack_multi (k = tap * Cin + ci); icoef: the input
+ * prologue table or NULL; bn_partials: [yh_conv_s2_blocks][2][Cout] or NULL.  Same results as yh_conv_fwd to fp32 summation
+ * order.  replaces: nn.Conv2d(k=3, s=2, p=1) forward (train.py:408-418, 593-597). */
+int yh_conv_s2_ok(int B, int H, int W, int Cin, int Cout);
+int yh_conv_s2_blocks(int B, int H, int W, int Cout);
+int yh_conv_s2_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias, float *y,
+                       int ldy, float *bn_partials, int B, int H, int W, int Cin, int Cout, void *stream);
 /* ---- input prologue (round 4) ----------------------------------------------------------------------------------------------
  * Every forward / weight-gradient entry point below has an `_act` form taking the prologue table of its x operand: icoef =
  * three rows [scale | shift | gate] of Cin floats, icoef_ld floats apart (NULL: the plain entry point).  The kernel reads the
@@ -542,7 +550,8 @@ enum {
     YH_OP_BF16_CONV_NARROW_BWD_WEIGHT, /* slots of YH_OP_CONV_BWD_WEIGHT + p[4] = dbias | NULL */
     YH_OP_SPPF_POOL3,                  /* p: x, y1, y2, y3;  i: ldx, ldy, B, H, W, C */
     YH_OP_CONV_LAT_FWD_FUSED,          /* slots of YH_OP_CONV_FWD_FUSED (p[1] = the k-quad interleaved pack of yh_lat_pack_multi) */
-    YH_OP_LAT_PACK_MULTI               /* p: descriptor table;  i: n */
+    YH_OP_LAT_PACK_MULTI,              /* p: descriptor table;  i: n */
+    YH_OP_CONV_S2_FWD                  /* slots of YH_OP_CONV_FWD (k = 3, s = 2 implied; p[1] = a yh_lat_pack_multi pack) */
 };
 /* Runs ops[0..n) in order on `stream`; stops at the first failure and returns its code
  * (failing index in *failed when non-NULL).  Two lanes: ops with lane == 1 run on the context's side

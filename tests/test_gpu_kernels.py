@@ -554,3 +554,52 @@ def test_latency_inference_conv(B, H, W, Cin, Cout, k, s, res, up, act):
     torch.cuda.synchronize()
     assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
     assert lib.yh_conv_lat_ok(B, H, W, Cin + 4, Cout, k, s) == 0                 # Cin % 8 != 0: not this kernel's problem
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
+    (2, 32, 32, 32, 64, False),      # two column tiles, 64-pixel blocks
+    (3, 20, 20, 64, 128, True),      # four column tiles; blocks span image boundaries (gap rows); input prologue
+    (2, 9, 11, 16, 32, True),        # odd sizes: ragged blocks, padding on every side
+    (1, 40, 40, 128, 256, False),    # two column workgroups per pixel block
+    (5, 6, 6, 8, 96, True),          # one chunk, three column tiles of the last workgroup unused... Cout = 96: ragged column workgroup
+])
+def test_stride2_lds_forward(B, H, W, Cin, Cout, act):
+    """conv_s2.hip: 3x3 stride-2 forward with the input patch staged through LDS, with and without the input prologue (producer
+    BatchNorm scale / shift + SiLU, every fifth channel linear), output, bias and the BatchNorm partial sums against fp64."""
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(B * 10 + H + Cin)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout)
+    assert lib.yh_conv_s2_ok(B, H, W, Cin, Cout) == 1
+    xin = x.double()
+    tab = None
+    if act:
+        sc, sh = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+        gate = (torch.arange(Cin) % 5 != 0).float()
+        ldc = rup4(Cin) + 4
+        tab = torch.zeros(3, ldc)
+        tab[0, :Cin], tab[1, :Cin], tab[2, :Cin] = sc, sh, gate
+        z = x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+        xin = torch.where(gate.bool()[None, :, None, None], z * torch.sigmoid(z), z)
+        tab = tab.cuda()
+    ref = F.conv2d(xin, w.double(), bias.double(), stride=2, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xd, wd, bd = nhwc(x), w.cuda(), bias.cuda()
+    ldw = rup4(Cout)
+    wq = torch.full((9 * Cin * ldw,), float("nan"), device="cuda")
+    desc = torch.cat([torch.tensor([wd.data_ptr(), wq.data_ptr()], dtype=torch.int64).view(torch.uint8),
+                      torch.tensor([Cout, Cin, 9, ldw], dtype=torch.int32).view(torch.uint8)]).cuda()
+    L.check(lib.yh_lat_pack_multi(desc.data_ptr(), 1, st))
+    nb = lib.yh_conv_s2_blocks(B, H, W, Cout)
+    part = torch.full((nb, 2, Cout), float("nan"), device="cuda")
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda")
+    L.check(lib.yh_conv_s2_fwd_act(xd.data_ptr(), Cin, tab.data_ptr() if act else None, tab.shape[1] if act else 0, wq.data_ptr(), ldw,
+                                   bd.data_ptr(), y.data_ptr(), Cout, part.data_ptr(), B, H, W, Cin, Cout, st))
+    torch.cuda.synchronize()
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-5
+    s = part.double().sum(0).cpu()
+    assert float((s[0] - ref.sum((0, 2, 3))).abs().max() / ref.abs().sum((0, 2, 3)).max()) < 1e-5
+    assert float((s[1] - (ref ** 2).sum((0, 2, 3))).abs().max() / (ref ** 2).sum((0, 2, 3)).max()) < 1e-5

@@ -56,7 +56,7 @@ def main():
 
     fa, fn = plan.fwd_ops
     ba, bn = plan.bwd_ops
-    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_BF16_CONV_FWD,
+    tf = time_ops(fa, fn, {L.OP_CONV_FWD, L.OP_CONV_S2_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_BF16_CONV_FWD,
                            L.OP_CONV_NARROW, L.OP_BF16_CONV_NARROW})
     DG = {L.OP_CONV_BWD_DATA, L.OP_CONV_WINO_BWD_DATA, L.OP_CONV_BWD_DATA_PAIR, L.OP_CONV_PW_BWD_DATA, L.OP_CONV_BWD_DATA_S2M,
           L.OP_BF16_CONV_BWD_DATA, L.OP_CONV_NARROW, L.OP_CONV_NARROW_DGRAD_S2, L.OP_BF16_CONV_NARROW, L.OP_BF16_CONV_NARROW_DGRAD_S2}
@@ -77,7 +77,7 @@ def main():
             return (i[3], i[4], i[5], i[7], i[6], 3, 1) if i[9] else (i[3], i[4], i[5], i[6], i[7], 3, i[8])
         if o.kind == L.OP_BF16_CONV_BWD_DATA and i[11] > 0:       # fused sibling pair: listed under the first conv's shape
             return (i[3], i[4], i[5], i[6], i[11], 1, 1)
-        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_DATA_S2M,
+        if o.kind in (L.OP_CONV_FWD, L.OP_CONV_S2_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_BWD_DATA, L.OP_CONV_BWD_DATA_S2M,
                       L.OP_BF16_CONV_FWD, L.OP_BF16_CONV_BWD_DATA, L.OP_CONV_NARROW_DGRAD_S2, L.OP_BF16_CONV_NARROW_DGRAD_S2):
             return (i[3], i[4], i[5], i[6], i[7], i[8], i[9])
         if o.kind == L.OP_CONV_WINO_BWD_DATA:

@@ -37,7 +37,7 @@ class YhOp(C.Structure):
  OP_BF16_PACK_MULTI, OP_BF16_CONV_FWD, OP_BF16_CONV_BWD_DATA, OP_BF16_CONV_BWD_WEIGHT, OP_BF16_COLSUM, OP_BF16_BN_SILU_FWD,
  OP_BF16_BN_SILU_BWD_REDUCE, OP_BF16_BN_SILU_BWD_APPLY, OP_BF16_MAXPOOL5_FWD, OP_BF16_MAXPOOL5_BWD,
  OP_FOLD_OIHW_MULTI, OP_CONV_WINO_FWD_FUSED, OP_CONV_PW_FWD_FUSED, OP_CONV_NARROW, OP_CONV_NARROW_DGRAD_S2, OP_CONV_NARROW_BWD_WEIGHT, OP_BF16_CONV_NARROW, OP_BF16_CONV_NARROW_DGRAD_S2,
- OP_BF16_CONV_NARROW_BWD_WEIGHT, OP_SPPF_POOL3, OP_CONV_LAT_FWD_FUSED, OP_LAT_PACK_MULTI) = range(1, 58)
+ OP_BF16_CONV_NARROW_BWD_WEIGHT, OP_SPPF_POOL3, OP_CONV_LAT_FWD_FUSED, OP_LAT_PACK_MULTI, OP_CONV_S2_FWD) = range(1, 59)
 
 _P3 = C.c_void_p * 3
 _I3 = C.c_int * 3
@@ -58,6 +58,9 @@ _SIGS = {
     "yh_fold_oihw_multi": (i32, [c_fp, i32, c_fp]),
     "yh_conv_wino_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_pw_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
+    "yh_conv_s2_ok": (i32, [i32, i32, i32, i32, i32]),
+    "yh_conv_s2_blocks": (i32, [i32, i32, i32, i32]),
+    "yh_conv_s2_fwd_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "yh_conv_lat_ok": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "yh_conv_lat_fwd_fused": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "yh_lat_pack_multi": (i32, [c_fp, i32, c_fp]),

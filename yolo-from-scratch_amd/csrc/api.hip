@@ -197,6 +197,9 @@ static int run_one(const yh_op &o, void *st) {
                                          (float *)p[4], i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], st);
         case YH_OP_LAT_PACK_MULTI:
             return yh_lat_pack_multi(p[0], i[0], st);
+        case YH_OP_CONV_S2_FWD:             /* slots of YH_OP_CONV_FWD */
+            return yh_conv_s2_fwd_act((const float *)p[0], i[0], (const float *)p[10], i[17], (const float *)p[1], i[1], (const float *)p[2],
+                                      (float *)p[3], i[2], (float *)p[4], i[3], i[4], i[5], i[6], i[7], st);
         default:
             yh_set_error("yh_run: unknown op kind %d", o.kind);
             return YH_E_BADARG;

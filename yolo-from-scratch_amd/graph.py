@@ -172,6 +172,7 @@ class ConvRec:
     narrow_f: bool = False  # forward on the direct kernel for the narrow high-resolution 3x3 layers
     narrow_b: bool = False  # stride-1 backward-data on the same kernel (flipped taps)
     narrow_w: bool = False  # weight gradient on the direct pixel-reduction kernel
+    s2l_f: bool = False     # forward on the LDS-staged 3x3 stride-2 kernel (conv_s2.hip)
     cin_k: int = 0          # bf16 plan: input channels the narrow kernels read (4 of the first layer's 8 padded ones)
     fwd2: bool = False      # forward fused with the sibling pointwise conv (one GEMM, N = cout1 + cout2)
     nblk: int = 0           # BatchNorm partial-sum rows written by the forward kernel
@@ -339,6 +340,8 @@ class Plan:
         if use_narrow and r.k == 3 and r.s == 2 and r.cin == 4 and r.x.ld == 4 and r.cout == 16 and r.ldwf == 16 \
                 and lib.yh_conv_narrow_ok(r.cin, r.cout, 3, r.s):
             r.narrow_f = True                     # first layer: the same direct MFMA kernel with CIN = 4 (padded) channels
+        r.s2l_f = bool(special and not r.narrow_f and r.k == 3 and r.s == 2 and r.cin == r.weight.shape[1] and r.x.ld % 4 == 0 and
+                       r.x.off % 4 == 0 and lib.yh_conv_s2_ok(r.x.B, r.x.H, r.x.W, r.cin, r.cout))
         r.narrow_b = bool(nar_ok and r.s == 1 and r.need_dx and lib.yh_conv_narrow_ok(r.cout, r.cin, 3, 1))
         if r.narrow_f:
             r.wino_f = False
@@ -409,7 +412,7 @@ class Plan:
         M = c.x.B * c.Ho * c.Wo
         if c.narrow_f:
             return c.cin == 16
-        if c.wino_f:
+        if c.wino_f or c.s2l_f:
             return True
         if c.fwd2:
             return bool(lib.yh_conv_pw_prologue_ok(M, c.cin, c.cout + c.pair.cout))
@@ -578,7 +581,10 @@ class Plan:
                     winos.append((r.weight.data_ptr(), r.wf.data_ptr(), r.cout, r.weight.shape[1], r.ldwf, 0))
                 if r.wino_b:
                     winos.append((r.weight.data_ptr(), r.wb.data_ptr(), r.cout, r.weight.shape[1], r.ldwb, 1))
-                gen_f = not (r.wino_f or r.pw_f)                       # layouts the generic pack kernel still has to write
+                if r.s2l_f:
+                    r.wf = torch.zeros(kk * r.cin * r.ldwf, **f32)
+                    latpacks.append((r.weight.data_ptr(), r.wf.data_ptr(), r.cout, r.weight.shape[1], kk, r.ldwf))
+                gen_f = not (r.wino_f or r.pw_f or r.s2l_f)            # layouts the generic pack kernel still has to write
                 gen_b = r.wb is not None and not (r.wino_b or r.pw_b or r.s2m_b)
                 if gen_f or gen_b:
                     packs.append((r.weight.data_ptr(), r.wf.data_ptr() if gen_f else 0, r.wb.data_ptr() if gen_b else 0,
@@ -616,6 +622,7 @@ class Plan:
                             raise NotImplementedError("fused sibling convolution traced on the side lane without a preceding fork")
                 else:
                     nblk = lib.yh_conv_narrow_blocks(r.x.B, r.x.H, r.x.W, r.cin, r.s) if r.narrow_f else \
+                        lib.yh_conv_s2_blocks(r.x.B, r.x.H, r.x.W, r.cout) if r.s2l_f else \
                         lib.yh_conv_wino_blocks(r.x.B, r.x.H, r.x.W) if r.wino_f else \
                         lib.yh_conv_pw_blocks(M, r.cin, r.cout) if r.pw_f else \
                         lib.yh_conv_fwd_blocks(r.x.B, r.x.H, r.x.W, r.cout, r.k, r.s)
@@ -627,7 +634,7 @@ class Plan:
                                           r.part if r.bn is not None else None],
                                        i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.s, 0, 0], lane=ln))
                     else:
-                        fwd.append(_op(L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else L.OP_CONV_FWD),
+                        fwd.append(_op(L.OP_CONV_S2_FWD if r.s2l_f else L.OP_CONV_WINO_FWD if r.wino_f else (L.OP_CONV_PW_FWD if r.pw_f else L.OP_CONV_FWD),
                                        p=[r.x.ptr(), r.wf, r.bias, ytarget if ytarget is not None else r.out.ptr(),
                                           r.part if r.bn is not None else None],
                                        i=[r.x.ld, r.ldwf, ldy, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s], lane=ln))
