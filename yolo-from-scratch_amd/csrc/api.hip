@@ -335,6 +335,8 @@ static int side_ready(yh_context *ctx) {
     return 1;
 }
 
+thread_local int yh_tls_side_lane = 0;
+
 extern "C" int yh_run(yh_context *ctx, const yh_op *ops, int n, void *stream, int *failed) {
     YH_REQUIRE(ops || n == 0, "yh_run: null op list");
     hipStream_t mainst = (hipStream_t)stream;
@@ -372,7 +374,11 @@ extern "C" int yh_run(yh_context *ctx, const yh_op *ops, int n, void *stream, in
                 if (!rc) rc = hip(hipStreamWaitEvent(ctx->side, ctx->fork, 0), "fork wait");
             }
             forked = true;
-            if (!rc) rc = run_one(ops[k], (void *)ctx->side);
+            if (!rc) {
+                yh_tls_side_lane = 1;                          // see common.h: the launchers may size for a shared CU
+                rc = run_one(ops[k], (void *)ctx->side);
+                yh_tls_side_lane = 0;
+            }
         } else {
             rc = run_one(ops[k], stream);
         }

@@ -11,6 +11,13 @@ void yh_set_error(const char *fmt, ...);
 int yh_ensure_dyn_smem(const void *fn, size_t bytes);
 // environment switches of the library, read once per process (api.hip)
 int yh_env_bf16_stream();
+// Set by yh_run around an op it launches on the context's side lane (the weight-gradient lane), 0 otherwise and for every direct call.
+// The split-K weight-gradient launchers of conv_pw.hip and conv_wgrad.hip read it: next to the main lane they reserve YH_SIDE_LDS_BYTES
+// of LDS per workgroup, i.e. ONE of their workgroups per CU, and leave the other half of the CU (registers, 76 KB of LDS) to the main
+// lane's kernels -- measured 17.06 -> 16.64 ms per training step (bs 64, fp32); alone they are 5 % slower that way, so direct calls and
+// YH_OVERLAP=0 runs keep their natural occupancy.  Sweep: 60 KB (two per CU) 16.91, 81-92 KB 16.65-16.71, 100 KB 16.76, 128 KB 16.97.
+extern thread_local int yh_tls_side_lane;
+constexpr size_t YH_SIDE_LDS_BYTES = 84 * 1024;
 
 // Pointers that are SELECTED at run time (tensor A or tensor B, the input or a zero page, a table entry) lose their address
 // space and compile to FLAT loads / stores.  A flat access counts on vmcnt AND lgkmcnt and may retire out of order, so every

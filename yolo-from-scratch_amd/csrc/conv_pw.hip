@@ -233,8 +233,13 @@ extern "C" int yh_conv_pw_bwd_weight_act(const float *x, int ldx, const float *i
     g.dy_bytes = (unsigned)(((M - 1) * lddy + Cout) * 4);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(nsplit, cdiv(Cin, 32 * XV), cdiv(Cout, 32 * DV));
-    const size_t smem = (size_t)4 * 32 * 32 * DV * sizeof(float);
-#define YH_PW_LAUNCH(xv, dv) hipLaunchKernelGGL((pw_wgrad_kernel<xv, dv>), grid, dim3(256), smem, st, g)
+    const bool shared_cu = yh_tls_side_lane != 0;              // next to the main lane: one workgroup per CU (common.h)
+    const size_t smem = shared_cu ? YH_SIDE_LDS_BYTES : (size_t)4 * 32 * 32 * DV * sizeof(float);
+#define YH_PW_LAUNCH(xv, dv)                                                                                   \
+    do {                                                                                                       \
+        if (shared_cu) if (int rc2 = yh_ensure_dyn_smem((const void *)pw_wgrad_kernel<xv, dv>, smem)) return rc2; \
+        hipLaunchKernelGGL((pw_wgrad_kernel<xv, dv>), grid, dim3(256), smem, st, g);                           \
+    } while (0)
     if (XV == 2 && DV == 4) YH_PW_LAUNCH(2, 4);
     else if (XV == 2 && DV == 2) YH_PW_LAUNCH(2, 2);
     else if (XV == 2) YH_PW_LAUNCH(2, 1);

@@ -331,8 +331,10 @@ int make_plan(Plan &pl, int B, int Hi, int Wi, int Cin, int Cout, int k, int s) 
 template <int NT, int XL, int DL, int MT>
 int launch_wgrad_cfg(const Plan &pl, hipStream_t st) {
     auto kern = wgrad_kernel<NT, XL, DL, MT>;
-    if (int rc = yh_ensure_dyn_smem((const void *)kern, pl.smem)) return rc;
-    hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.ntiles), dim3(256), pl.smem, st, pl.g);
+    // next to the main lane: one workgroup per CU (common.h)
+    const size_t smem = yh_tls_side_lane && pl.smem < YH_SIDE_LDS_BYTES ? YH_SIDE_LDS_BYTES : pl.smem;
+    if (int rc = yh_ensure_dyn_smem((const void *)kern, smem)) return rc;
+    hipLaunchKernelGGL(kern, dim3(pl.nsplit, pl.ntiles), dim3(256), smem, st, pl.g);
     YH_CHECK_LAUNCH("wgrad");
     return 0;
 }

@@ -184,7 +184,6 @@ class ConvRec:
     x_fused: bool = False   # the input view has virtual channels: forward / weight-gradient kernels run the input prologue
     yp: int = 0             # address and pixel stride of the raw conv output (private tensor `y`, or the `out` view when virtual)
     ldy: int = 0
-    bacc: Optional[torch.Tensor] = None     # [2][cout] int64: fixed-point totals of the BatchNorm backward (zeroed by bn_finalize)
     dyp: int = 0            # where the BatchNorm backward writes dY: over Y in place, or (virtual) into the private tensor `y` -- the
     lddy: int = 0           # raw output in the shared buffer is still being read by the consumers' weight gradients on the side lane
 
@@ -601,7 +600,6 @@ class Plan:
                         else:
                             c.yp, c.ldy = c.dyp, c.lddy
                         c.coef = torch.empty(4 * c.cout, **f32)
-                        c.bacc = torch.zeros(2 * c.cout, device=dev, dtype=torch.int64)
                         c.part = torch.empty(max(nblk, lib.yh_bn_bwd_blocks(M, c.cout)) * 2 * c.cout, **f32)
 
                 if r.fwd2:
@@ -648,7 +646,7 @@ class Plan:
                                    p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
                                       r.bn.running_var if track else None, r.coef,
                                       r.bn.num_batches_tracked if track else None,
-                                      r.out.icoef_ptr(0) if r.virtual else None, r.out.icoef_ptr(1) if r.virtual else None, r.bacc],
+                                      r.out.icoef_ptr(0) if r.virtual else None, r.out.icoef_ptr(1) if r.virtual else None],
                                    i=[nblk, r.cout], f=[mom, r.bn.eps], l=[M], lane=ln))
                     if not r.virtual:
                         rf = self._res_fused(r)               # the residual is a raw conv output: normalised on the fly
@@ -784,7 +782,6 @@ class Plan:
             if r.bn is not None:
                 r.y = torch.empty(r.x.B, r.Ho, r.Wo, r.cout, **b16)
                 r.coef = torch.empty(4 * r.cout, **f32)
-                r.bacc = torch.zeros(2 * r.cout, device=dev, dtype=torch.int64)
                 r.part = torch.empty(max(r.nblk, lib.yh_bn_bwd_blocks(M, r.cout)) * 2 * r.cout, **f32)
                 if r.narrow_f:
                     fwd.append(_op(L.OP_BF16_CONV_NARROW, p=[r.x.ptr(), r.wf, r.bias, r.y, r.part],
@@ -797,7 +794,7 @@ class Plan:
                 fwd.append(_op(L.OP_BN_FINALIZE,
                                p=[r.part, r.bn.weight, r.bn.bias, r.bn.running_mean if track else None,
                                   r.bn.running_var if track else None, r.coef, r.bn.num_batches_tracked if track else None,
-                                  None, None, r.bacc],
+                                  None, None],
                                i=[r.nblk, r.cout], f=[mom, r.bn.eps], l=[M], lane=ln))
                 fwd.append(_op(L.OP_BF16_BN_SILU_FWD,
                                p=[r.y, r.coef, r.residual.ptr() if r.residual else None, r.out.ptr()],
@@ -848,7 +845,6 @@ class Plan:
                 nb = lib.yh_bn_bwd_blocks(M, r.cout)
                 ops.append(_op(L.OP_BF16_BN_SILU_BWD_REDUCE, p=[r.out.gptr(), r.y, r.coef, r.part],
                                i=[r.out.ldg, r.cout, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
-                ops[-1].p[9] = r.bacc.data_ptr()
                 if r.residual is not None:
                     dres, racc = self._grad_target(r.residual)
                     ldres = r.residual.ldg
@@ -858,7 +854,6 @@ class Plan:
                                p=[r.out.gptr(), r.y, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)], grad_of[id(r.bn.bias)],
                                   r.y, dres],
                                i=[r.out.ldg, r.cout, nb, r.cout, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
-                ops[-1].p[9] = r.bacc.data_ptr()
                 dy, lddy, kcout = r.y.data_ptr(), r.cout, r.cout
                 self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
             else:       # head: the loss wrote a bf16 gradient zero-padded to a multiple of 8 channels
@@ -959,7 +954,6 @@ class Plan:
                 nb = lib.yh_bn_bwd_blocks(M, r.cout)
                 ops.append(_op(L.OP_BN_SILU_BWD_REDUCE, p=[r.out.gptr(), r.yp, r.coef, r.part],
                                i=[r.out.ld, r.ldy, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
-                ops[-1].p[9] = r.bacc.data_ptr()              # totals through fixed-point accumulators: no finalize launch
                 if r.residual is not None:
                     dres, racc = self._grad_target(r.residual)
                     ldres = r.residual.ld
@@ -969,7 +963,6 @@ class Plan:
                                p=[r.out.gptr(), r.yp, r.coef, r.part, r.bn.weight, grad_of[id(r.bn.weight)],
                                   grad_of[id(r.bn.bias)], r.dyp, dres],
                                i=[r.out.ld, r.ldy, nb, r.lddy, ldres, racc, r.cout, r.Ho, r.Wo, int(r.upsample)], l=[M]))
-                ops[-1].p[9] = r.bacc.data_ptr()
                 bn_ops[id(r)] = (r, len(ops) - 2, len(ops) - 1)
                 if r.residual is not None:
                     writers.append((len(ops) - 1, r.residual, None))
