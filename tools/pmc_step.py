@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel SQ counter table of one training step from tools/pmc_step.sh.
-usage: python tools/pmc_step.py gpurun_out/pmcstep_<tag> profiles/r03_pmc_step_<tag>.json
+usage: python tools/pmc_step.py gpurun_out/pmcstep_<tag> profiles/r04_pmc_step_<tag>.json
 Columns: launches, MFMA-pipe busy share of the SIMD cycles the kernel was resident (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs x
 8 CUs per SE-record ... reported as busy cycles per launch and as a share of GRBM-equivalent time via SQ_BUSY_CYCLES), vector instructions
 per wave-cycle, and the share of wave time spent issuing VALU / waiting on an instruction."""

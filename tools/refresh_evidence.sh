@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/refresh_evidence.sh  -- the bench lines of every BASELINE shape (fp32 and bf16), the model
-# sizes n/m/l/x and the bs=1 inference latency into gpurun_out/ev_*.json (copied into profiles/r03_* by tools/store_evidence.py)
+# sizes n/m/l/x and the bs=1 inference latency into gpurun_out/ev_*.json (copied into profiles/r04_* by tools/store_evidence.py)
 set -e
 O=gpurun_out
 python3 bench.py > $O/ev_bench_f32.json 2> $O/ev_bench_f32.err

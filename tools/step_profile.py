@@ -8,7 +8,7 @@ at 64 bytes; checked here against the nchw_to_nhwc launch whose traffic is known
     YH_OVERLAP=0 rocprofv3 --kernel-trace   -d $R/gpurun_out/sp_trace -o t -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extras
     YH_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/sp_fetch -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras
     YH_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/sp_write -o c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras
-    python tools/step_profile.py gpurun_out/sp_trace/t_results.db gpurun_out/sp_fetch/c_results.db gpurun_out/sp_write/c_results.db profiles/r03_step_profile_f32.json
+    python tools/step_profile.py gpurun_out/sp_trace/t_results.db gpurun_out/sp_fetch/c_results.db gpurun_out/sp_write/c_results.db profiles/r04_step_profile_f32.json
 (the same with YH_BENCH_DTYPE=bf16 YH_BENCH_SHAPE=80,640,64 for the bf16 path)
 """
 import json
@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from provenance import stamp
 
 FWD_CONV = ("gather_gemm_kernel", "wino_kernel", "wino_lds_kernel", "pw_gemm_kernel", "pw_tile_kernel", "pw_stream_kernel", "bf16_gemm_kernel",
-            "bf16_fstream_kernel", "narrow_conv_kernel", "narrow_first_bf16_kernel", "narrow_s2_16x32_bf16_kernel")
+            "bf16_fstream_kernel", "narrow_conv_kernel", "narrow_first_bf16_kernel", "narrow_s2_16x32_bf16_kernel", "s2_lds_kernel", "lat_conv_kernel")
 DGRAD_ONLY = ("narrow_dgrad_s2_kernel", "narrow_dgrad_s2_bf16_kernel")
 WGRAD = ("wgrad_kernel", "wino_wgrad_kernel", "wino_wgrad_lds_kernel", "pw_wgrad_kernel", "bf16_wgrad_kernel", "bf16_wgrad_stream_kernel", "wgrad_reduce")
 

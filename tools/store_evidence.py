@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copy the files written by tools/refresh_evidence.sh (gpurun_out/ev_*.json) into profiles/r03_*: the bench lines as they are,
-the model-size runs condensed into profiles/r03_sizes.json.  Every file gets the provenance stamp of the tree it ran from
+"""Copy the files written by tools/refresh_evidence.sh (gpurun_out/ev_*.json) into profiles/r04_*: the bench lines as they are,
+the model-size runs condensed into profiles/r04_sizes.json.  Every file gets the provenance stamp of the tree it ran from
 (the bench lines carry none of their own)."""
 import json
 import os
@@ -19,7 +19,7 @@ def main():
                  "bench_bf16_80_1280_16", "infer_latency"):
         d = json.load(open(os.path.join(G, f"ev_{name}.json")))
         d["stamp"] = st
-        json.dump(d, open(os.path.join(P, f"r03_{name}.json"), "w"), indent=1)
+        json.dump(d, open(os.path.join(P, f"r04_{name}.json"), "w"), indent=1)
     runs = {}
     for sz in "nmlx":
         for dt in ("f32", "bf16"):
@@ -31,7 +31,7 @@ def main():
                                                                          "algorithmic_gflop_per_step", "conv_tflops")}}
     json.dump({"note": "informational: the reference's other model sizes (train.py:1346-1352), nc=1 640x640, one training step; "
                        "l / x at batch 32; not the reported metric", "stamp": st, "runs": runs},
-              open(os.path.join(P, "r03_sizes.json"), "w"), indent=1)
+              open(os.path.join(P, "r04_sizes.json"), "w"), indent=1)
     print("stored", st)
 
 
