@@ -82,7 +82,8 @@ def time_forward_convs(trainer, plan, imgs, targets, steps):
         for kind, e0, e1 in evs:
             ms = e0.elapsed_time(e1)
             per_kind[kind] = per_kind.get(kind, 0.0) + ms
-            if kind in (L.OP_CONV_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_BF16_CONV_FWD, L.OP_CONV_NARROW, L.OP_BF16_CONV_NARROW):
+            if kind in (L.OP_CONV_FWD, L.OP_CONV_S2_FWD, L.OP_CONV_WINO_FWD, L.OP_CONV_PW_FWD, L.OP_CONV_PW_FWD2, L.OP_BF16_CONV_FWD, L.OP_CONV_NARROW,
+                        L.OP_BF16_CONV_NARROW):
                 conv_ms += ms
                 n_launch += 1
         plan.generation += 1
@@ -268,11 +269,13 @@ def roofline_f32(model, trainer, imgs, targets, nc, img, batch, size):
             "executed_mfma_frac": round(executed / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "kernel": "forward convolutions: wino_lds_kernel (3x3 stride-1 layers, Winograd F(2x2,3x3) with the input patch staged "
                       "through LDS: executes 4/9 of the algorithmic multiplies) + pw_tile_kernel / pw_stream_kernel (1x1) + "
-                      "gather_gemm_kernel (stride-2, wide 1x1) + narrow_conv_kernel (16-channel 3x3 layers, stem[3], stem[0]); since round 4 "
+                      "s2_lds_kernel (3x3 stride-2 layers, patch staged through LDS) + gather_gemm_kernel (wide 1x1) + narrow_conv_kernel "
+                      "(16-channel 3x3 layers, stem[3], stem[0]); since round 4 "
                       "most of these kernels also apply their input's BatchNorm + SiLU while staging it (89 % of the normalised elements "
                       "are never materialised), so their time includes what the separate bn_silu_fwd pass used to cost",
             "narrow_ms_per_step": round(per_kind.get(L.OP_CONV_NARROW, 0.0), 3),
             "gather_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_FWD, 0.0), 3),
+            "s2_lds_ms_per_step": round(per_kind.get(L.OP_CONV_S2_FWD, 0.0), 3),
             "wino_ms_per_step": round(per_kind.get(L.OP_CONV_WINO_FWD, 0.0), 3),
             "pw_gemm_ms_per_step": round(per_kind.get(L.OP_CONV_PW_FWD, 0.0) + per_kind.get(L.OP_CONV_PW_FWD2, 0.0), 3),
             "wino_algorithmic_gflop_per_step": round(flops_wino / 1e9, 2),
