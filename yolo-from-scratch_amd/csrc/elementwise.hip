@@ -220,8 +220,21 @@ __global__ void colsum_stage1(const T *__restrict__ x, int ldx, int64_t M, int C
     for (int cb = 0; cb < C; cb += cw) {
         int c = cb + c_in;
         float s = 0.f;
-        if (c < C)
-            for (int64_t r = r0 + r_in; r < r1; r += rg) s += ld1(x + r * ldx + c);
+        if (c < C) {
+            // eight independent rows per trip (one 4-byte load in flight per thread ran the nc = 80 head biases, C = 255, at 1 TB/s);
+            // fixed order of the additions: reproducible
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+            int64_t r = r0 + r_in;
+            const T *px = x + c;
+            for (; r + 7 * rg < r1; r += 8 * rg) {
+                const float v0 = ld1(px + r * ldx), v1 = ld1(px + (r + rg) * ldx), v2 = ld1(px + (r + 2 * rg) * ldx),
+                            v3 = ld1(px + (r + 3 * rg) * ldx), v4 = ld1(px + (r + 4 * rg) * ldx), v5 = ld1(px + (r + 5 * rg) * ldx),
+                            v6 = ld1(px + (r + 6 * rg) * ldx), v7 = ld1(px + (r + 7 * rg) * ldx);
+                s += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+            }
+            for (; r < r1; r += rg) s += ld1(px + r * ldx);
+            s = ((s + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        }
         red[t] = s;
         __syncthreads();
         if (r_in == 0 && c < C) {
