@@ -161,26 +161,25 @@ def _stream_batch(y, i, nc, S, B):
 
 
 def test_bf16_gradients_agree_after_warmup():
-    """VERDICT r2 item 7.  The 0.90-0.95 cosines at initialisation are the conditioning of the random network, not a defect
-    of the bf16 path (file header): the SAME comparison 100+ Adam steps into training -- bf16 and fp32 HIP gradients at
-    identical weights on a fresh batch -- must agree at cosine >= 0.985 on average, >= 0.97 for nine tensors in ten, >= 0.93
-    for every one, and 2e-3 relative in the loss.  Single points of a trajectory still swing: along one fp32 trajectory the
-    loss gap read 5.0e-5 after 60 steps, 8.5e-3 after 100 and 1.2e-4 after 150 (tools/bf16_grad_agreement.py), and any change of
-    an fp32 summation order (a kernel's BatchNorm partial sums) moves the whole trajectory.  So the comparison is taken at THREE
-    checkpoints (100, 125, 150 steps): at least two must meet every bound, and all three the loose ones (every cosine >= 0.93,
-    mean >= 0.98, loss within 1e-2)."""
+    """VERDICT r2 item 7, ADVICE r3.  The 0.90-0.95 cosines at initialisation are the conditioning of the random network, not a
+    defect of the bf16 path (file header).  The comparison is taken at ONE fixed weight set -- the deterministic fp32 HIP run of 120
+    Adam steps on the seeded stream -- and on SIX fresh batches: bf16 and fp32 gradients at identical weights.  One bound holds for
+    every batch (loss within 1e-2 relative, every tensor's cosine >= 0.90); the gradients AVERAGED over the six batches (what a
+    larger batch would see: the rounding noise of single small batches averages out, a systematic bf16 error would not) must agree
+    at cosine >= 0.93 for every tensor, >= 0.97 for nine in ten, >= 0.985 on average, and the mean loss gap must be <= 3e-3.
+    (Round 3 read three checkpoints of the trajectory and accepted two of three: which points were sampled decided the result.)"""
     y = api()
     nc, S, B = 3, 320, 4
     torch.manual_seed(0)
     m = y.YOLO(num_classes=nc, img_size=S).cuda()
     tr = y.HipTrainer(m, lr=1e-3, max_norm=10.0, dtype="f32")
     names = [n for n, p in m.named_parameters() if p.dim() == 4]
-    x, tg = _stream_batch(y, 999, nc, S, B)
-    done, good, report = 0, 0, []
-    for upto in (100, 125, 150):
-        while done < upto:
-            tr.step(*_stream_batch(y, done, nc, S, B))
-            done += 1
+    for i in range(120):
+        tr.step(*_stream_batch(y, i, nc, S, B))
+    gaps, report = [], []
+    mean_g = {dt: {n: 0.0 for n in names} for dt in ("f32", "bf16")}
+    for k in range(6):
+        x, tg = _stream_batch(y, 999 + k, nc, S, B)
         res = {}
         for dtype in ("f32", "bf16"):
             m.set_compute_dtype(dtype)
@@ -189,17 +188,20 @@ def test_bf16_gradients_agree_after_warmup():
             out = y.yolo_loss_multiscale(m(x), tg, m.anchors, nc)
             out[0].backward()
             res[dtype] = (float(out[0].detach()), {n: p.grad.detach().reshape(-1).double().clone() for n, p in m.named_parameters() if n in names})
-        m.set_compute_dtype("f32")
-        m.zero_grad()
+            for n in names:
+                mean_g[dtype][n] = mean_g[dtype][n] + res[dtype][1][n]
         gap = abs(res["bf16"][0] - res["f32"][0]) / abs(res["f32"][0])
-        cos = {n: _cos(res["f32"][1][n], res["bf16"][1][n]) for n in names if float(res["f32"][1][n].norm()) > 0}
-        assert len(cos) >= 55
-        srt = sorted(cos.values())
-        worst, p10, mean = srt[0], srt[len(srt) // 10], sum(srt) / len(srt)
-        report.append((upto, round(gap, 5), round(worst, 4), round(p10, 4), round(mean, 4)))
-        assert worst >= 0.93 and mean >= 0.98 and gap <= 1e-2, report
-        good += int(gap <= 2e-3 and worst >= 0.93 and p10 >= 0.97 and mean >= 0.985)
-    assert good >= 2, report
+        cos = [_cos(res["f32"][1][n], res["bf16"][1][n]) for n in names if float(res["f32"][1][n].norm()) > 0]
+        gaps.append(gap)
+        report.append((k, round(gap, 5), round(min(cos), 4), round(sum(cos) / len(cos), 4)))
+        assert len(cos) >= 55 and gap <= 1e-2 and min(cos) >= 0.90, report
+    m.set_compute_dtype("f32")
+    m.zero_grad()
+    cos = sorted(_cos(mean_g["f32"][n], mean_g["bf16"][n]) for n in names if float(mean_g["f32"][n].norm()) > 0)
+    worst, p10, mean = cos[0], cos[len(cos) // 10], sum(cos) / len(cos)
+    report.append(("mean", round(sum(gaps) / len(gaps), 5), round(worst, 4), round(p10, 4), round(mean, 4)))
+    print(report)
+    assert sum(gaps) / len(gaps) <= 3e-3 and worst >= 0.93 and p10 >= 0.97 and mean >= 0.985, report
 
 
 def test_bf16_trajectory_tracks_fp32():
