@@ -166,7 +166,8 @@ def test_bf16_gradients_agree_after_warmup():
     Adam steps on the seeded stream -- and on SIX fresh batches: bf16 and fp32 gradients at identical weights.  One bound holds for
     every batch (loss within 1e-2 relative, every tensor's cosine >= 0.90); the gradients AVERAGED over the six batches (what a
     larger batch would see: the rounding noise of single small batches averages out, a systematic bf16 error would not) must agree
-    at cosine >= 0.93 for every tensor, >= 0.97 for nine in ten, >= 0.985 on average, and the mean loss gap must be <= 3e-3.
+    at cosine >= 0.96 for every tensor, >= 0.98 for nine in ten, >= 0.99 on average, and the mean loss gap must be <= 3e-3
+    (measured: 0.990 / 0.992 / 0.996, mean gap 1.05e-3; single batches: gap <= 4.7e-3, worst cosine 0.92).
     (Round 3 read three checkpoints of the trajectory and accepted two of three: which points were sampled decided the result.)"""
     y = api()
     nc, S, B = 3, 320, 4
@@ -201,7 +202,7 @@ def test_bf16_gradients_agree_after_warmup():
     worst, p10, mean = cos[0], cos[len(cos) // 10], sum(cos) / len(cos)
     report.append(("mean", round(sum(gaps) / len(gaps), 5), round(worst, 4), round(p10, 4), round(mean, 4)))
     print(report)
-    assert sum(gaps) / len(gaps) <= 3e-3 and worst >= 0.93 and p10 >= 0.97 and mean >= 0.985, report
+    assert sum(gaps) / len(gaps) <= 3e-3 and worst >= 0.96 and p10 >= 0.98 and mean >= 0.99, report
 
 
 def test_bf16_trajectory_tracks_fp32():
