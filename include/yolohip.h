@@ -472,7 +472,9 @@ int yh_bf16_pack_multi(const void *table, int n, void *stream);
  * [yh_bf16_conv_fwd_blocks(B, Hi, Wi, Cin, Cout, k, s, y_f32, ldx, ldy)][2][Cout] sums / sums of squares of the STORED (bf16-rounded)
  * values, or NULL.  Stride-1 layers with 16 / 32 / 64 / 128 input channels (3x3: up to 64) and bf16 output run as a flat
  * pixel stream with ONE partial row per persistent workgroup (conv_bf16_stream.hip); the rest on the gather GEMM with one
- * row per 128 output pixels (yh_bf16_conv_blocks(M)). */
+ * row per 128 output pixels (yh_bf16_conv_blocks(M)).  The route is a function of shapes and strides only (the same predicate sizes the
+ * partial-row table): when ldx and ldy are multiples of 8, x, wf and y must be 16-byte aligned (argument error otherwise); views with
+ * other strides run on the gather kernel at any 2-byte alignment.  yh_bf16_conv_bwd_data: the same rule for lddy / lddx. */
 int yh_bf16_conv_fwd(const void *x, int ldx, const void *wf, int ldwf, const float *bias, void *y, int ldy, int y_f32,
                      float *bn_partials, int B, int Hi, int Wi, int Cin, int Cout, int k, int s, void *stream);
 int yh_bf16_conv_blocks(int64_t M);

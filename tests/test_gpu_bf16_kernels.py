@@ -527,3 +527,27 @@ def test_bf16_narrow_layer_kernels(B, H, W, Cin, Cout, s):
     dw2 = torch.empty_like(dw)
     L.check(lib.yh_bf16_conv_narrow_bwd_weight(*args, dw2.data_ptr(), None, ws.data_ptr(), nws, B, H, W, cin_k, min(Cin, cin_k), Cout, s, st), "wgrad")
     assert torch.equal(dw, dw2)
+
+
+def test_bf16_conv_stream_eligible_views_must_be_aligned():
+    """the bf16 convolution entry points pick the flat-stream or the gather kernel from shapes and strides alone (the planner
+    sizes the BatchNorm partial rows from the same predicate, which cannot see pointers).  For a stream-eligible problem (both strides
+    multiples of 8) a view at a channel offset of 4 (8 bytes) is therefore an argument error with a message that says so -- not a
+    silent change of route with a different partial-row count; the same view with a stride that is not a multiple of 8 runs on the
+    gather kernel (test_bf16_conv_direct_store_variants)."""
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, H, W, cin, cout, k, s = 2, 8, 8, 32, 32, 3, 1
+    ld = cin + 8
+    x = torch.zeros(B, H, W, ld, dtype=torch.bfloat16, device="cuda")
+    wf = torch.zeros(k * k * cin * rup8(cout), dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(B, H, W, cout, dtype=torch.bfloat16, device="cuda")
+    args = (wf.data_ptr(), rup8(cout), None, y.data_ptr(), cout, 0, None, B, H, W, cin, cout, k, s, st)
+    assert lib.yh_bf16_conv_fwd(x.data_ptr(), ld, *args) == 0, lib.yh_last_error()
+    rc = lib.yh_bf16_conv_fwd(x.data_ptr() + 8, ld, *args)
+    assert rc != 0 and b"16-byte aligned" in lib.yh_last_error()
+    dx = torch.zeros(B, H, W, ld, dtype=torch.bfloat16, device="cuda")
+    rc = lib.yh_bf16_conv_bwd_data(y.data_ptr(), cout, None, 0, wf.data_ptr(), rup8(cin), dx.data_ptr() + 8, ld, B, H, W, cin, cout, k, s, 0, st)
+    assert rc != 0 and b"16-byte aligned" in lib.yh_last_error()
+    torch.cuda.synchronize()

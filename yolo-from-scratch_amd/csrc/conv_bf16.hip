@@ -937,8 +937,15 @@ extern "C" int yh_bf16_conv_fwd(const void *x, int ldx, const void *wf, int ldwf
     YH_REQUIRE((k == 1 || k == 3) && (s == 1 || s == 2) && !(k == 1 && s == 2), "bf16_conv_fwd: unsupported k=%d s=%d", k, s);
     YH_REQUIRE(x && wf && y && B > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "bf16_conv_fwd: bad argument");
     YH_REQUIRE(ldx >= Cin && ldy >= Cout, "bf16_conv_fwd: ld smaller than channel count");
-    if (fwd_on_stream(B, Hi, Wi, Cin, Cout, k, s, y_f32, ldx, ldy))
+    if (fwd_on_stream(B, Hi, Wi, Cin, Cout, k, s, y_f32, ldx, ldy)) {
+        // Which kernel runs is decided from shapes and strides alone -- yh_bf16_conv_fwd_blocks sizes the partial-sum table from the same
+        // predicate and cannot see pointers -- so for stream-eligible problems (both strides multiples of 8) the 16-byte view contract of
+        // the header is an argument check here, not a silent change of route.  Views with other strides run on the gather kernel at any
+        // 2-byte alignment (test_bf16_conv_direct_store_variants).
+        YH_REQUIRE(((((uintptr_t)x) | ((uintptr_t)wf) | ((uintptr_t)y)) & 15) == 0,
+                   "bf16_conv_fwd: with ldx and ldy multiples of 8, x, wf and y must be 16-byte aligned views");
         return fwd_stream(x, ldx, wf, ldwf, bias, y, ldy, bn_partials, B, Hi, Wi, Cin, Cout, k, stream);
+    }
     const int p = k / 2;
     BfGemm g{};
     fill_common(g, x, ldx, wf, ldwf, Hi, Wi, Cin, B);
@@ -965,8 +972,11 @@ extern "C" int yh_bf16_conv_bwd_data(const void *dy, int lddy, const void *dy2, 
     YH_REQUIRE(lddy >= (dy2 ? kcout1 : Cout) && lddx >= Cin, "bf16_conv_bwd_data: ld smaller than channel count");
     YH_REQUIRE(!dy2 || (k == 1 && kcout1 > 0 && kcout1 < Cout), "bf16_conv_bwd_data: the two-source form is pointwise only");
     const int p = k / 2, Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
-    if (use_stream() && yh_bf16_fstream_ok(B, Hi, Wi, Cout, Cin, k, s) && lddy % 8 == 0 && lddx % 8 == 0)
+    if (use_stream() && yh_bf16_fstream_ok(B, Hi, Wi, Cout, Cin, k, s) && lddy % 8 == 0 && lddx % 8 == 0) {
+        YH_REQUIRE(((((uintptr_t)dy) | ((uintptr_t)dy2) | ((uintptr_t)wb) | ((uintptr_t)dx)) & 15) == 0,
+                   "bf16_conv_bwd_data: with lddy and lddx multiples of 8, dy, dy2, wb and dx must be 16-byte aligned views");
         return bwd_data_stream(dy, lddy, dy2, kcout1, wb, ldwb, dx, lddx, B, Hi, Wi, Cin, Cout, k, accumulate, stream);
+    }
     BfGemmSet gs{};
     int ncls = 0;
     for (int ph = 0; ph < s; ++ph)
