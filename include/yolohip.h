@@ -51,6 +51,8 @@ int yh_destroy(yh_context *ctx);          /* waits for the side stream, then fre
  *   YH_GENERIC=1      planner (graph.py), when a plan is traced: every convolution on the generic gather-GEMM / wgrad kernels
  *                     instead of the specialised families (the two product paths cross-check each other in the tests)
  *   YH_EVAL_FAST=0    planner: eval plans keep every layer on the gather GEMM (no fused Winograd / pointwise forms)
+ *   YH_FUSE_ACT=0     planner: no producer activation is applied by its consumers (every BatchNorm + SiLU pass is launched and the
+ *                     normalised tensors exist in memory, as up to round 3) -- A/B switch and cross-check of the fused plans
  *   YH_BENCH_SHAPE / YH_BENCH_DTYPE / YH_BENCH_SIZE   bench.py only: informational shapes, never the reported metric
  * Diagnostic builds are compile-time: make EXTRA=-DYH_PW_STAMPS | -DYH_WINO_STAMPS | -DYH_BF_STAMPS | -DYH_WGS_TUNE. */
 int yh_context_set_overlap(yh_context *ctx, int enable);
