@@ -186,6 +186,7 @@ class ConvRec:
     ldy: int = 0
     dyp: int = 0            # where the BatchNorm backward writes dY: over Y in place, or (virtual) into the private tensor `y` -- the
     lddy: int = 0           # raw output in the shared buffer is still being read by the consumers' weight gradients on the side lane
+    kcout_b: int = 0        # K rows of the backward-data pack (> cout: a head whose gradient rows are zero-padded; 0: cout)
 
 
 @dataclass
@@ -258,8 +259,13 @@ class Plan:
             # a plain conv output on the bf16 path (the detection heads): fp32 values for the fp32 loss, bf16 gradient
             # with the channel axis zero-padded to a multiple of 8 (the backward GEMMs read 16-byte pieces)
             out = self.new_buffer(x.B, Ho * f, Wo * f, cout, "head", dtype=torch.float32, grad_C=_rup8(cout)).view()
+        if out is None and bn is None:
+            # a plain conv output (the detection heads, 3 (5 + nc) = 18 / 255 channels): dense values for the loss, but a gradient whose
+            # pixel rows are zero-padded to a multiple of 4 channels -- the backward GEMMs and the bias column sum then read 16-byte
+            # pieces (at nc = 80 the 255-float rows ran every one of them on its scalar-load variant)
+            out = self.new_buffer(x.B, Ho * f, Wo * f, cout, "head", grad_C=_rup4(cout)).view()
         if out is None:
-            out = self.new_buffer(x.B, Ho * f, Wo * f, cout if bn is None else _rup4(cout)).view()
+            out = self.new_buffer(x.B, Ho * f, Wo * f, _rup4(cout)).view()
         if self.bf16 and bn is not None and (out.off % 8 or out.ld % 8):
             raise NotImplementedError("the bf16 path needs output views aligned to 8 channels")
         if self.bf16 and bn is None and out.buf.dtype != torch.float32:
@@ -562,7 +568,10 @@ class Plan:
                     r.wb = torch.empty(6 * r.cout * r.ldwb, **f32)
                     s2m_packs.append(_op(L.OP_PACK_WEIGHTS_S2M, p=[r.weight, r.wb], i=[r.cout, r.cin, r.ldwb]))
                 else:
-                    r.wb = torch.empty((16 if r.wino_b else kk) * r.cout * r.ldwb, **f32) if r.need_dx else None
+                    # K rows of the backward pack: a 1x1 head reads dY rows zero-padded to a multiple of 4 channels against zero rows here
+                    r.kcout_b = _rup4(r.cout) if (r.bn is None and r.k == 1 and not (r.wino_b or r.pw_b) and r.out.ldg >= _rup4(r.cout)) else r.cout
+                    r.wb = (torch.zeros if r.kcout_b != r.cout else torch.empty)((16 if r.wino_b else kk) * r.kcout_b * r.ldwb, **f32) \
+                        if r.need_dx else None
                 second = r.pair is not None and not r.pair_first
                 assert not r.fwd2 or r.pw_f                  # same eligibility rule (decided at pair detection)
                 if r.pw_f:                                   # the pointwise pack writes only the conv's own columns
@@ -969,10 +978,14 @@ class Plan:
                 dy, lddy = r.dyp, r.lddy
                 self.grad_ready[id(r.bn.weight)] = self.grad_ready[id(r.bn.bias)] = len(ops)
             else:
-                dy, lddy = r.out.gptr(), r.out.ld
+                dy, lddy = r.out.gptr(), r.out.ldg                 # head: the loss / autograd wrote rows zero-padded to ldg channels
+            kcout = (r.kcout_b or r.cout) if r.bn is None else r.cout
             fuse_bias = r.bias is not None and r.narrow_w          # the narrow weight-gradient kernel also sums dY's columns
             if r.bias is not None and not fuse_bias:
-                ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, r.cout], l=[M]))
+                # head biases: sum the zero-padded multiple of 4 so the vector kernel applies; the extra column sums are exact zeros
+                # and land in the 4-float padding every tensor has in the flat gradient buffer
+                cs = _rup4(r.cout) if (r.bn is None and _rup4(r.cout) <= lddy) else r.cout
+                ops.append(_op(L.OP_COLSUM, p=[dy, grad_of[id(r.bias)], self.ws], i=[lddy, cs], l=[M]))
                 self.grad_ready[id(r.bias)] = len(ops)
             ops.append(_op(L.OP_CONV_NARROW_BWD_WEIGHT if r.narrow_w else L.OP_CONV_WINO_BWD_WEIGHT if r.wino_w else
                            (L.OP_CONV_PW_BWD_WEIGHT if r.pw_w else L.OP_CONV_BWD_WEIGHT),
@@ -1017,7 +1030,7 @@ class Plan:
                                    i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, acc]))
                 else:
                     ops.append(_op(L.OP_CONV_BWD_DATA, p=[dy, r.wb, dst],
-                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, r.cout, r.k, r.s, acc]))
+                                   i=[lddy, r.ldwb, r.x.ld, r.x.B, r.x.H, r.x.W, r.cin, kcout, r.k, r.s, acc]))
         # (folding the BatchNorm-backward sums into the epilogue of the backward-data GEMM that finishes a layer's gradient was
         # built, tested and measured in round 2: backward-data 5.74 -> 7.26 ms against 0.85 ms saved in the reduce pass; retired)
         return ops

@@ -193,7 +193,7 @@ class HipTrainer:
         plan.run_forward(st)
         run_loss_kernel([v.buf.data for v in heads], targets, [v.buf.grad for v in heads],
                         _anchors18(model.anchors), [v.H for v in heads], plan.B, nc, None, None, self.loss_out,
-                        self._loss_ws, st, dpred_bf16=plan.bf16, dpred_ld=[v.ldg for v in heads] if plan.bf16 else None)
+                        self._loss_ws, st, dpred_bf16=plan.bf16, dpred_ld=[v.ldg for v in heads])
         begin = 0
         for end, rng in self._segments[1]:
             plan.run_backward(st, begin, end)       # yh_run joins its side stream before returning
