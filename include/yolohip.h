@@ -51,6 +51,8 @@ int yh_destroy(yh_context *ctx);          /* waits for the side stream, then fre
  *   YH_GENERIC=1      planner (graph.py), when a plan is traced: every convolution on the generic gather-GEMM / wgrad kernels
  *                     instead of the specialised families (the two product paths cross-check each other in the tests)
  *   YH_EVAL_FAST=0    planner: eval plans keep every layer on the gather GEMM (no fused Winograd / pointwise forms)
+ *   YH_PW_X6=1        library, once per process (EXPERIMENTAL, default off): the forward 1x1 convolutions it supports run on the split-bf16
+ *                     form of the fp32 GEMM (yh_conv_pw_fwd_x6 below)
  *   YH_FUSE_ACT=0     planner: no producer activation is applied by its consumers (every BatchNorm + SiLU pass is launched and the
  *                     normalised tensors exist in memory, as up to round 3) -- A/B switch and cross-check of the fused plans
  *   YH_BENCH_SHAPE / YH_BENCH_DTYPE / YH_BENCH_SIZE   bench.py only: informational shapes, never the reported metric
@@ -227,6 +229,15 @@ int yh_conv_bwd_weight_prologue_ok(int B, int Hi, int Wi, int Cin, int Cout, int
 int yh_conv_pw_prologue_ok(int64_t M, int Cin, int Cout);       /* the streaming and tiled pointwise forward kernels have a prologue */
 int yh_conv_pw_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias, float *y, int ldy,
                        float *bn_partials, int64_t M, int Cin, int Cout, void *stream);
+/* EXPERIMENTAL (round 4): the same forward GEMM on the bf16 matrix pipe -- every fp32 operand split into three bf16 terms in registers,
+ * six exact bf16 products per fp32 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 0.375 of the fp32 instruction's matrix time,
+ * error against fp64 BELOW the fp32 instruction's (only the accumulation rounds).  Same contract and results (to fp32 rounding) as
+ * yh_conv_pw_fwd_act; Cin in {16, 32, 64, 128}, Cout <= 128 (Cin * Cout small enough for the weights' three planes in LDS), M >= 4096:
+ * yh_conv_pw_x6_blocks returns the partial-sum rows, or 0 when the kernel cannot run the problem.  Not used by the planner unless
+ * YH_PW_X6=1 (see csrc/conv_pw.hip for what was measured). */
+int yh_conv_pw_x6_blocks(int64_t M, int Cin, int Cout);
+int yh_conv_pw_fwd_x6(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias, float *y, int ldy,
+                      float *bn_partials, int64_t M, int Cin, int Cout, void *stream);
 int yh_conv_pw_fwd2_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias1, float *y1,
                         int ldy1, float *bn_partials1, int cout1, const float *bias2, float *y2, int ldy2, float *bn_partials2, int cout2,
                         int64_t M, int Cin, void *stream);

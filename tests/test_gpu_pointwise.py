@@ -145,3 +145,58 @@ def test_pointwise_backward_weight(M, Cin, Cout, ldd):
     L.check(lib.yh_conv_pw_bwd_weight(xd.data_ptr(), Cin, dyb.data_ptr(), ldd, dw2.data_ptr(), ws.data_ptr(), nws, M, Cin, Cout, st))
     assert torch.equal(dw, dw2)
     assert lib.yh_conv_pw_bwd_weight(xd.data_ptr(), Cin, dyb.data_ptr(), ldd, dw2.data_ptr(), ws.data_ptr(), 10, M, Cin, Cout, st) != 0
+
+
+@pytest.mark.parametrize("M,Cin,Cout", [(40003, 64, 128), (70001, 64, 64), (33000, 32, 32), (50000, 16, 16), (36000, 128, 64), (4100, 32, 24),
+                                        (150001, 64, 96)])
+def test_pointwise_forward_on_the_bf16_pipe(M, Cin, Cout):
+    """yh_conv_pw_fwd_x6: the fp32 GEMM as six exact bf16 products per fp32 product (operands split into three bf16 terms), fp32
+    accumulation.  Held to the fp64 reference at the fp32 kernels' tolerance AND to the claim that makes it admissible as an fp32 path:
+    its error is not larger than 1.5x that of the fp32-MFMA kernel on the same data (measured: smaller).  Views with ld > C, ragged M and N,
+    bias, BatchNorm partial sums, and the input prologue."""
+    L = _lib()
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(M + Cin + Cout)
+    x, w, bias = torch.randn(M, Cin), torch.randn(Cout, Cin) / Cin ** 0.5, torch.randn(Cout)
+    wd = w.cuda()
+    ldwf = rup4(Cout)
+    qf = torch.zeros(Cin * ldwf, device="cuda")
+    pack(L, lib, wd, qf, None, ldwf, rup4(Cin))
+    ldx, offx = Cin + 12, 8
+    xb = torch.full((M, ldx), 5.0, device="cuda")
+    xb[:, offx:offx + Cin] = x.cuda()
+    ldy, offy = Cout + 4, 4
+    nblk = lib.yh_conv_pw_x6_blocks(M, Cin, Cout)
+    assert nblk > 0
+    bd = bias.cuda()
+    for act in (False, True):
+        if act:
+            ic = torch.zeros(3, rup4(Cin) + 4, device="cuda")
+            ic[0] = torch.rand(rup4(Cin) + 4, device="cuda") + 0.5
+            ic[1] = torch.randn(rup4(Cin) + 4, device="cuda") * 0.3
+            ic[2, :Cin:2] = 1.0                                  # SiLU on every other channel
+            z = x.double() * ic[0, :Cin].double().cpu() + ic[1, :Cin].double().cpu()
+            xin = torch.where(ic[2, :Cin].cpu() != 0, z * torch.sigmoid(z), z)
+            icp, icld = ic.data_ptr(), ic.shape[1]
+        else:
+            xin, icp, icld = x.double(), None, 0
+        ref = xin @ w.double().t() + bias.double()
+        outs = {}
+        for name, fn in (("x6", lib.yh_conv_pw_fwd_x6), ("f32", lib.yh_conv_pw_fwd_act)):
+            if name == "f32" and act and not lib.yh_conv_pw_prologue_ok(M, Cin, Cout):
+                continue                                         # the fp32 kernel of this shape has no prologue: fp64 reference only
+            yb = torch.full((M, ldy), 7.0, device="cuda")
+            nb = nblk if name == "x6" else lib.yh_conv_pw_blocks(M, Cin, Cout)
+            part = torch.zeros(nb * 2 * Cout, device="cuda")
+            L.check(fn(xb.data_ptr() + 4 * offx, ldx, icp, icld, qf.data_ptr(), ldwf, bd.data_ptr(), yb.data_ptr() + 4 * offy, ldy,
+                       part.data_ptr(), M, Cin, Cout, st), name)
+            y = yb[:, offy:offy + Cout]
+            assert bool((yb[:, :offy] == 7.0).all())
+            outs[name] = (rel_err(y, ref), y, part.view(nb, 2, Cout).sum(0))
+        e6, y6, p6 = outs["x6"]
+        e32 = outs["f32"][0] if "f32" in outs else None
+        assert e6 < (2e-5 if act else 2e-6), (e6, e32)
+        assert e32 is None or e6 <= 1.5 * e32 + 1e-8, (e6, e32)
+        yd = y6.double().cpu()
+        assert rel_err(p6[0], yd.sum(0)) < 1e-4 and rel_err(p6[1], (yd * yd).sum(0)) < 1e-4

@@ -77,6 +77,8 @@ _SIGS = {
     "yh_conv_bwd_weight_prologue_ok": (i32, [i32, i32, i32, i32, i32, i32, i32]),
     "yh_conv_pw_prologue_ok": (i32, [i64, i32, i32]),
     "yh_conv_pw_fwd_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i64, i32, i32, c_fp]),
+    "yh_conv_pw_x6_blocks": (i32, [i64, i32, i32]),
+    "yh_conv_pw_fwd_x6": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i64, i32, i32, c_fp]),
     "yh_conv_pw_fwd2_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i64, i32, c_fp]),
     "yh_conv_pw_bwd_weight_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i64, i64, i32, i32, c_fp]),
     "yh_conv_narrow_act": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp]),

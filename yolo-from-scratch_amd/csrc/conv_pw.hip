@@ -805,6 +805,200 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const PwG g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fp32 GEMM on the bf16 matrix pipe ("x6" form, round 4).  MI355X multiplies fp32 at 157 TFLOP/s and bf16 at 2.5 PFLOP/s: an
+// fp32 operand split into three bf16 terms (x = h + m + l exactly up to 2^-24 |x|: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m))
+// makes a product a b = hh + (hm + mh) + (hl + lh + mm) + O(2^-24): SIX exact bf16 products accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 -- 6 x 32 cycles per 16 channels of a 32 x 32 tile against 8 x 64 for v_mfma_f32_32x32x2_f32, 0.375 of the
+// matrix time, and measured MORE accurate than the fp32 instruction (each product is exact, only the fp32 accumulation rounds: relative
+// error 1.2e-7 against 3.0e-7 for K = 64 ... 2304 against an fp64 reference).  The weights' three planes are built once per workgroup in
+// LDS in the B-operand layout ([plane][16-channel chunk][k half][column] x 8 bf16: conflict-free 16-byte reads); a wave owns 32 pixels x
+// NT x 32 columns per trip, loads its pixels' K channels as fp32 (two float4 per chunk and lane: k = 16 c + 8 (lane >> 5) ...), applies
+// the input prologue, splits in registers and runs 6 NT MFMAs per chunk; the next group's loads are in flight meanwhile.  Same epilogue,
+// partial-sum rows and sibling-pair outputs as pw_stream_kernel.
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef float xf32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void x6_split(const xf32x8 v, xbf16x8 &h, xbf16x8 &m, xbf16x8 &l) {
+    h = __builtin_convertvector(v, xbf16x8);
+    const xf32x8 r1 = v - __builtin_convertvector(h, xf32x8);
+    m = __builtin_convertvector(r1, xbf16x8);
+    const xf32x8 r2 = r1 - __builtin_convertvector(m, xf32x8);
+    l = __builtin_convertvector(r2, xbf16x8);
+}
+
+template <int NT, int KC, bool ACT>         // NT x 32 columns, K = 16 KC
+__global__ __launch_bounds__(256) void pw_x6_kernel(const PwG g) {
+    constexpr int NP = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    xbf16x8 *const bp = (xbf16x8 *)xsm;                                  // [3][KC][2][NP]
+    float *const red = (float *)(xsm + (size_t)3 * KC * 2 * NP * 16);   // [4][NP][2]
+    float *const ctab = red + 4 * NP * 2;                                // [3][16 KC]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g.in, 0, g.in_bytes, 0x00020000);
+    for (int i = t; i < KC * 2 * NP; i += 256) {
+        const int n = i % NP, cg = i / NP;                               // cg = 2 c + k half: channels 8 cg ... 8 cg + 7
+        xf32x8 w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = 0.f;
+        if (n < g.ldw) {
+            const f32x4 w0 = *(const f32x4 *)(g.Wq + ((size_t)(2 * cg) * g.ldw + n) * 4);
+            const f32x4 w1 = *(const f32x4 *)(g.Wq + ((size_t)(2 * cg + 1) * g.ldw + n) * 4);
+            w = xf32x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        }
+        xbf16x8 h, m, l;
+        x6_split(w, h, m, l);
+        bp[(0 * KC * 2 + cg) * NP + n] = h;
+        bp[(1 * KC * 2 + cg) * NP + n] = m;
+        bp[(2 * KC * 2 + cg) * NP + n] = l;
+    }
+    if (ACT)
+        for (int i = t; i < 3 * 16 * KC; i += 256) ctab[i] = g.icoef[(i / (16 * KC)) * g.icoef_ld + i % (16 * KC)];
+    __syncthreads();
+
+    bool nok[NT];
+    float bias[NT], csum[NT], csq[NT];
+    gfloat *ob[NT];
+    int ldo[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + lr;
+        nok[j] = n < g.N;
+        const bool second = n >= g.N1;
+        const int nl = second ? n - g.N1 : n;
+        const gfloat *bpt = second ? yh_global(g.bias2) : yh_global(g.bias);
+        bias[j] = (bpt && nok[j]) ? bpt[nl] : 0.f;
+        ob[j] = (second ? yh_global(g.out2) : yh_global(g.out)) + nl;
+        ldo[j] = second ? g.ldo2 : g.ldo;
+        csum[j] = csq[j] = 0.f;
+    }
+    const bool plain = NP <= g.N;                          // wave-uniform: every lane's column exists
+    const int ngroups = (g.M + 31) >> 5, stride = gridDim.x * 4;
+    auto load = [&](int grp, f32x4 (&a)[KC][2]) {
+        const int p = grp * 32 + lr;
+        const unsigned off = (((unsigned)p * (unsigned)g.ldi + 8u * lh) * 4u) | ((unsigned)(p >= g.M || grp >= ngroups) << 31);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            a[c][0] = buf_load<4>(r1, off + (unsigned)c * 64u);
+            a[c][1] = buf_load<4>(r1, off + (unsigned)c * 64u + 16u);
+        }
+    };
+    auto compute = [&](int grp, const f32x4 (&a)[KC][2]) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            xf32x8 v = {a[c][0][0], a[c][0][1], a[c][0][2], a[c][0][3], a[c][1][0], a[c][1][1], a[c][1][2], a[c][1][3]};
+            if (ACT) {
+                const int k0 = 16 * c + 8 * lh;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = yh_prologue(v[e], ctab[k0 + e], ctab[16 * KC + k0 + e], ctab[32 * KC + k0 + e]);
+            }
+            xbf16x8 ah, am, al;
+            x6_split(v, ah, am, al);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const xbf16x8 bh = bp[((0 * KC + c) * 2 + lh) * NP + j * 32 + lr];
+                const xbf16x8 bm = bp[((1 * KC + c) * 2 + lh) * NP + j * 32 + lr];
+                const xbf16x8 bl = bp[((2 * KC + c) * 2 + lh) * NP + j * 32 + lr];
+                // smallest terms first
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            }
+        }
+        const int p0 = grp * 32;
+        if (plain && p0 + 32 <= g.M) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                gfloat *o = ob[j] + (size_t)(p0 + 4 * lh) * ldo[j];
+                const size_t step = (size_t)ldo[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[j][r] + bias[j];
+                    *o = v;
+                    o += (r & 3) == 3 ? 5 * step : step;
+                    csum[j] += v;
+                    csq[j] += v * v;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nok[j] && p < g.M) {
+                    const float v = acc[j][r] + bias[j];
+                    ob[j][(size_t)p * ldo[j]] = v;
+                    csum[j] += v;
+                    csq[j] += v * v;
+                }
+            }
+    };
+    f32x4 aA[KC][2], aB[KC][2];
+    int grp = blockIdx.x * 4 + wave;
+    load(grp, aA);
+    for (; grp < ngroups; grp += 2 * stride) {
+        load(grp + stride, aB);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(grp, aA);
+        __builtin_amdgcn_sched_barrier(0);
+        load(grp + 2 * stride, aA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp + stride < ngroups) compute(grp + stride, aB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (g.stats) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float sm = csum[j] + __shfl_xor(csum[j], 32), q = csq[j] + __shfl_xor(csq[j], 32);
+            if (lh == 0) { red[(wave * NP + j * 32 + lr) * 2] = sm; red[(wave * NP + j * 32 + lr) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        if (t < NP && t < g.N) {
+            const float a0 = (red[t * 2] + red[(NP + t) * 2]) + (red[(2 * NP + t) * 2] + red[(3 * NP + t) * 2]);
+            const float a1 = (red[t * 2 + 1] + red[(NP + t) * 2 + 1]) + (red[(2 * NP + t) * 2 + 1] + red[(3 * NP + t) * 2 + 1]);
+            const int n = t;
+            gfloat *sp = n >= g.N1 ? yh_global(g.stats2) : yh_global(g.stats);
+            const int C = n >= g.N1 ? g.N - g.N1 : g.N1, nl = n >= g.N1 ? n - g.N1 : n;
+            sp[((size_t)blockIdx.x * 2 + 0) * C + nl] = a0;
+            sp[((size_t)blockIdx.x * 2 + 1) * C + nl] = a1;
+        }
+    }
+}
+
+// Status: EXPERIMENTAL, off unless YH_PW_X6=1 (read once per process).  Alone the kernel is faster (1x1 64->64 sibling pairs at 80^2:
+// 61 -> 44 us per launch, 32->32 at 160^2 91 -> 81, 128->64 at 80^2 97 -> 78 us), but inside the training step the launches AROUND it
+// slow down by more than it gains (step 16.61 -> 16.70 ms with 1024 workgroups per launch, 16.9-17.05 with 512, 16.63 with 256; the
+// serial per-launch sum shows the other kernels +0.16 ms) -- the chip's clock after a dense bf16-MFMA burst is the suspect, not yet
+// measured.  Kept as the tested starting point for moving the fp32 GEMMs to the bf16 pipe: yh_conv_pw_fwd_x6 forces it.
+inline bool pw_x6_shape_ok(int64_t M, int K, int N) {
+    return M >= 4096 && K % 16 == 0 && K >= 16 && K <= 128 && N <= 128 && (int64_t)K * (N > 64 ? 128 : (N > 32 ? 64 : 32)) <= 64 * 128;
+}
+inline bool pw_x6_can(int64_t M, int K, int N) {         // ... and an instantiation exists (K = 16, 32, 64, 128)
+    return pw_x6_shape_ok(M, K, N) && (K == 16 || K == 32 || K == 64 || K == 128);
+}
+inline bool pw_x6_takes(int64_t M, int K, int N) {       // the automatic route (planner and launcher agree: both call this)
+    static const bool on = getenv("YH_PW_X6") && getenv("YH_PW_X6")[0] == '1';
+    return on && pw_x6_can(M, K, N);
+}
+inline int pw_x6_blocks(int64_t M) {                     // one workgroup per CU (measured best inside the step: see above)
+    int64_t b = ((M + 31) / 32 + 3) / 4;
+    return (int)(b > 256 ? 256 : b);
+}
+inline size_t pw_x6_smem(int K, int NT) {
+    const int KC = K / 16, NP = 32 * NT;
+    return (size_t)3 * KC * 2 * NP * 16 + (size_t)4 * NP * 2 * 4 + (size_t)3 * 16 * KC * 4;
+}
+
 // streaming form: K in {16, 32, 64}, N <= 64 and enough pixels to stream (measured: 160^2 32->32 0.104 -> 0.085 ms = 4.9 TB/s;
 // N = 128 with K = 32 was slower than the tiled kernel and is left to it)
 inline bool pw_use_stream(int64_t M, int K, int N) {
@@ -861,7 +1055,7 @@ __global__ void pw_pack_multi_kernel(const PwPackDesc *__restrict__ tab) {
     }
 }
 
-int launch_pw_gemm(PwG &g, hipStream_t st) {
+int launch_pw_gemm(PwG &g, hipStream_t st, bool force_x6 = false) {
     YH_REQUIRE(g.K % 8 == 0 && g.K1 % 8 == 0 && g.K1 > 0 && g.K1 <= g.K && g.ldi % 4 == 0 && (((uintptr_t)g.in | (uintptr_t)g.Wq) & 15) == 0 &&
                    (!g.in2 || (((uintptr_t)g.in2) & 15) == 0) && g.ldw >= g.N && g.M > 0,
                "conv_pw: channels must be multiples of 8, operands 16-byte addressable");
@@ -872,8 +1066,38 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
     const int NT = g.N > 64 ? 4 : (g.N > 32 ? 2 : 1);
     const bool fused = g.act || g.up2 || g.res;          // the streaming form has no inference epilogue
     YH_REQUIRE(!g.icoef || (!fused && !g.in2 && (((uintptr_t)g.icoef) & 15) == 0 && g.icoef_ld % 4 == 0 && g.icoef_ld >= g.K &&
-                            (pw_use_stream(g.M, g.K, g.N) || (g.K % 32 == 0 && pw_use_tile(g.K, g.N)))),
+                            (force_x6 || pw_x6_takes(g.M, g.K, g.N) || pw_use_stream(g.M, g.K, g.N) || (g.K % 32 == 0 && pw_use_tile(g.K, g.N)))),
                "conv_pw: the input prologue runs on the streaming and the tiled forward kernels only (yh_conv_pw_prologue_ok)");
+    if (!fused && !g.in2 && !g.accumulate && (force_x6 ? pw_x6_can(g.M, g.K, g.N) : pw_x6_takes(g.M, g.K, g.N))) {
+        dim3 sg(pw_x6_blocks(g.M));
+        const int KC = g.K / 16;
+        const size_t smem = pw_x6_smem(g.K, NT);
+        int rc = 0;
+        bool ok = true;
+#define YH_X6(nt, kc)                                                                                         \
+    do {                                                                                                      \
+        if (g.icoef) {                                                                                        \
+            rc = yh_ensure_dyn_smem((const void *)pw_x6_kernel<nt, kc, true>, smem);                          \
+            if (!rc) hipLaunchKernelGGL((pw_x6_kernel<nt, kc, true>), sg, dim3(256), smem, st, g);           \
+        } else {                                                                                              \
+            rc = yh_ensure_dyn_smem((const void *)pw_x6_kernel<nt, kc, false>, smem);                         \
+            if (!rc) hipLaunchKernelGGL((pw_x6_kernel<nt, kc, false>), sg, dim3(256), smem, st, g);          \
+        }                                                                                                     \
+    } while (0)
+#define YH_X6K(nt)                                                                                            \
+    do {                                                                                                      \
+        if (KC == 1) YH_X6(nt, 1); else if (KC == 2) YH_X6(nt, 2); else if (KC == 4) YH_X6(nt, 4);            \
+        else if (KC == 8) YH_X6(nt, 8); else ok = false;                                                      \
+    } while (0)
+        if (NT == 1) YH_X6K(1); else if (NT == 2) YH_X6K(2); else YH_X6K(4);
+#undef YH_X6K
+#undef YH_X6
+        if (ok) {
+            if (rc) return rc;
+            YH_CHECK_LAUNCH("pw_x6");
+            return 0;
+        }
+    }
     if (!fused && pw_use_stream(g.M, g.K, g.N)) {
         dim3 sg(pw_stream_blocks(g.M));
         const int KC = g.K / 8;
@@ -948,6 +1172,7 @@ int launch_pw_gemm(PwG &g, hipStream_t st) {
 }  // namespace
 
 extern "C" int yh_conv_pw_blocks(int64_t M, int K, int Cout) {
+    if (pw_x6_takes(M, K, Cout)) return pw_x6_blocks(M);
     if (pw_use_stream(M, K, Cout)) return pw_stream_blocks(M);
     if (pw_use_tile(K, Cout)) return pw_tile_gx(M, Cout);
     const int NT = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
@@ -964,7 +1189,7 @@ extern "C" int yh_pw_pack_multi(const void *table, int n, void *stream) {
 }
 
 extern "C" int yh_conv_pw_prologue_ok(int64_t M, int Cin, int Cout) {
-    return (pw_use_stream(M, Cin, Cout) || (Cin % 32 == 0 && pw_use_tile(Cin, Cout))) ? 1 : 0;
+    return (pw_x6_takes(M, Cin, Cout) || pw_use_stream(M, Cin, Cout) || (Cin % 32 == 0 && pw_use_tile(Cin, Cout))) ? 1 : 0;
 }
 extern "C" int yh_conv_pw_fwd_act(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias,
                                   float *y, int ldy, float *bn_partials, int64_t M, int Cin, int Cout, void *stream);
@@ -980,6 +1205,18 @@ extern "C" int yh_conv_pw_fwd_act(const float *x, int ldx, const float *icoef, i
     g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = bn_partials;
     g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
     return launch_pw_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int yh_conv_pw_x6_blocks(int64_t M, int Cin, int Cout) { return pw_x6_can(M, Cin, Cout) ? pw_x6_blocks(M) : 0; }
+extern "C" int yh_conv_pw_fwd_x6(const float *x, int ldx, const float *icoef, int icoef_ld, const float *wq, int ldw, const float *bias,
+                                 float *y, int ldy, float *bn_partials, int64_t M, int Cin, int Cout, void *stream) {
+    YH_REQUIRE(x && wq && y && M > 0 && M < (1ll << 30) && ldx >= Cin && ldy >= Cout, "conv_pw_fwd_x6: bad argument");
+    YH_REQUIRE(pw_x6_can(M, Cin, Cout), "conv_pw_fwd_x6: unsupported problem (yh_conv_pw_x6_blocks == 0)");
+    PwG g{};
+    g.icoef = icoef; g.icoef_ld = icoef_ld;
+    g.in = x; g.Wq = wq; g.bias = bias; g.out = y; g.stats = bn_partials;
+    g.ldi = ldx; g.ldw = ldw; g.ldo = ldy; g.M = (int)M; g.K = Cin; g.K1 = Cin; g.N = Cout;
+    return launch_pw_gemm(g, (hipStream_t)stream, true);
 }
 
 extern "C" int yh_conv_pw_fwd_fused(const float *x, int ldx, const float *wq, int ldw, const float *bias, const float *res, int ldr,
