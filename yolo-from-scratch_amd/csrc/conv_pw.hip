@@ -978,8 +978,8 @@ __global__ __launch_bounds__(256) void pw_x6_kernel(const PwG g) {
 // Status: EXPERIMENTAL, off unless YH_PW_X6=1 (read once per process).  Alone the kernel is faster (1x1 64->64 sibling pairs at 80^2:
 // 61 -> 44 us per launch, 32->32 at 160^2 91 -> 81, 128->64 at 80^2 97 -> 78 us), but inside the training step the launches AROUND it
 // slow down by more than it gains (step 16.61 -> 16.70 ms with 1024 workgroups per launch, 16.9-17.05 with 512, 16.63 with 256; the
-// serial per-launch sum shows the other kernels +0.16 ms) -- the chip's clock after a dense bf16-MFMA burst is the suspect, not yet
-// measured.  Kept as the tested starting point for moving the fp32 GEMMs to the bf16 pipe: yh_conv_pw_fwd_x6 forces it.
+// serial per-launch sum shows the other kernels +0.16 ms): a fixed fp32 Winograd layer runs 9 % slower behind a burst of these
+// launches than behind the fp32 ones (tools/x6_aftermath.py) -- the chip's clock after dense bf16-MFMA work.  Kept as the tested starting point for moving the fp32 GEMMs to the bf16 pipe: yh_conv_pw_fwd_x6 forces it.
 inline bool pw_x6_shape_ok(int64_t M, int K, int N) {
     return M >= 4096 && K % 16 == 0 && K >= 16 && K <= 128 && N <= 128 && (int64_t)K * (N > 64 ? 128 : (N > 32 ? 64 : 32)) <= 64 * 128;
 }
