@@ -241,14 +241,24 @@ int yh_ensure_dyn_smem(const void *fn, size_t bytes) {
 //                    kernels of conv_bf16_stream.hip (A/B switch)
 // (YH_OVERLAP is per context: yh_create.)  Everything else that used to be an environment knob is a constant now; diagnostic
 // builds (in-kernel stamps, tile sweeps) are compile-time: make EXTRA=-DYH_..._STAMPS / -DYH_WGS_TUNE.
+// YH_PW_X6=1        (experimental) the forward 1x1 convolutions it supports on the split-bf16 form of the fp32 GEMM (conv_pw.hip)
 static std::once_flag g_env_once;
-static int g_bf16_stream = 1;
-int yh_env_bf16_stream() {
+static int g_bf16_stream = 1, g_pw_x6 = 0;
+static void read_env_once() {
     std::call_once(g_env_once, [] {
         const char *e = getenv("YH_BF16_STREAM");
         g_bf16_stream = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("YH_PW_X6");
+        g_pw_x6 = (e && e[0] == '1') ? 1 : 0;
     });
+}
+int yh_env_bf16_stream() {
+    read_env_once();
     return g_bf16_stream;
+}
+int yh_env_pw_x6() {
+    read_env_once();
+    return g_pw_x6;
 }
 
 // ---- execution context ("no global mutable state besides the explicit handle") ---------------------------

@@ -11,6 +11,7 @@ void yh_set_error(const char *fmt, ...);
 int yh_ensure_dyn_smem(const void *fn, size_t bytes);
 // environment switches of the library, read once per process (api.hip)
 int yh_env_bf16_stream();
+int yh_env_pw_x6();
 // Set by yh_run around an op it launches on the context's side lane (the weight-gradient lane), 0 otherwise and for every direct call.
 // The split-K weight-gradient launchers of conv_pw.hip and conv_wgrad.hip read it: next to the main lane they reserve YH_SIDE_LDS_BYTES
 // of LDS per workgroup, i.e. ONE of their workgroups per CU, and leave the other half of the CU (registers, 76 KB of LDS) to the main

@@ -987,8 +987,7 @@ inline bool pw_x6_can(int64_t M, int K, int N) {         // ... and an instantia
     return pw_x6_shape_ok(M, K, N) && (K == 16 || K == 32 || K == 64 || K == 128);
 }
 inline bool pw_x6_takes(int64_t M, int K, int N) {       // the automatic route (planner and launcher agree: both call this)
-    static const bool on = getenv("YH_PW_X6") && getenv("YH_PW_X6")[0] == '1';
-    return on && pw_x6_can(M, K, N);
+    return yh_env_pw_x6() && pw_x6_can(M, K, N);
 }
 inline int pw_x6_blocks(int64_t M) {                     // one workgroup per CU (measured best inside the step: see above)
     int64_t b = ((M + 31) / 32 + 3) / 4;
