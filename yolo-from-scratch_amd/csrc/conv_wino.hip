@@ -44,6 +44,8 @@ struct Wino {
     const float *icoef;             // input prologue table [scale | shift | gate] (icoef_ld floats apart): input = z = x * scale[k] + shift[k],
     int icoef_ld;                   // then silu(z) where gate[k] != 0; applied while the patch is staged; null = plain input
     int TH, R, C, ncb;              // tile rows per image; tile rows x tile columns per workgroup (R C <= 32); column blocks per tile row
+    unsigned dm[6];                 // division by multiplication (fdiv) for the block's index arithmetic: ncol, ncb, TH, C, 2 C + 2, 2 TH + 2
+    int ds[6];
     int PCh, plane, bufsz, toff_ofs;// half-row stride and plane stride of the patch (float4 units); one patch buffer, tile-offset table (floats)
 #ifdef YH_WINO_STAMPS
     unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps
@@ -292,14 +294,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
     const int nwg = gridDim.x, orig = blockIdx.x;                  // XCD-aware bijective remap (see wino_kernel)
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tgrp = lin / g.ncol, colb = lin - tgrp * g.ncol;
+    const int tgrp = fdiv(lin, g.dm[0], g.ds[0]), colb = lin - tgrp * g.ncol;
     const int n0 = colb * BNW;
-    const int rbk = tgrp / g.ncb, cbk = tgrp - rbk * g.ncb;
+    const int rbk = fdiv(tgrp, g.dm[1], g.ds[1]), cbk = tgrp - rbk * g.ncb;
     const int g0 = rbk * g.R, c0 = cbk * g.C;                      // first linear tile row (over B * TH) and first tile column
-    const int b0 = g0 / g.TH, ty0 = g0 - b0 * g.TH;
+    const int b0 = fdiv(g0, g.dm[2], g.ds[2]), ty0 = g0 - b0 * g.TH;
     const int GT = g.B * g.TH;
     const int Reff = min(g.R, GT - g0), Ceff = min(g.C, g.TW - c0);
-    const int cross = (g0 + Reff - 1) / g.TH - b0;                 // image boundaries inside the block: two extra patch rows each
+    const int cross = fdiv(g0 + Reff - 1, g.dm[2], g.ds[2]) - b0;                 // image boundaries inside the block: two extra patch rows each
     const int rows_needed = 2 * Reff + 2 + 2 * cross;
     const int PC = 2 * g.C + 2;
 
@@ -310,9 +312,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
     int *const toff = (int *)(smem + g.toff_ofs);
     int rdA[2], rdB[2];                                            // float offsets of patch rows ra / rb of this lane's tile, per column parity
     {
-        int r = lr / g.C, c = lr - r * g.C;
+        int r = fdiv(lr, g.dm[3], g.ds[3]), c = lr - r * g.C;
         const bool tv = r < Reff && c < Ceff;
-        const int grow = g0 + r, b = grow / g.TH, ty = grow - b * g.TH;
+        const int grow = g0 + r, b = fdiv(grow, g.dm[2], g.ds[2]), ty = grow - b * g.TH;
         if (wave == 0 && lh == 0) toff[lr] = tv ? (b * g.H + 2 * ty) * g.W + 2 * (c0 + c) : -1;
         const int prow0 = tv ? 2 * r + 2 * (b - b0) : 0;           // empty slots read tile 0's pixels (in bounds; results never stored)
         if (!tv) c = 0;
@@ -330,11 +332,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, NT == 1 
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int pid = t + 256 * k, pix = pid >> 1;
-        const int prow = pix / PC, pcol = pix - prow * PC;
+        const int prow = fdiv(pix, g.dm[4], g.ds[4]), pcol = pix - prow * PC;
         int b, iy;
         const int seg0 = 2 * (g.TH - ty0) + 2;                     // patch rows of the first image
         if (prow < seg0) { b = b0; iy = 2 * ty0 - 1 + prow; }
-        else { const int pr = prow - seg0, sgm = pr / (2 * g.TH + 2); b = b0 + 1 + sgm; iy = pr - sgm * (2 * g.TH + 2) - 1; }
+        else { const int pr = prow - seg0, sgm = fdiv(pr, g.dm[5], g.ds[5]); b = b0 + 1 + sgm; iy = pr - sgm * (2 * g.TH + 2) - 1; }
         const int ix = 2 * c0 - 1 + pcol;
         const bool ok = b < g.B && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
         gofs[k] = pid < npieces ? (ok ? ((b * g.H + iy) * g.W + ix) * g.ldi + 4 * qq : -1) : -2;
@@ -1027,6 +1029,10 @@ int launch_lds_np(Wino &g, const WinoGeom &gm, hipStream_t st) {
     if (!dbgbuf) (void)hipMalloc((void **)&dbgbuf, (size_t)1 << 24);
     g.dbg = getenv("YH_WINO_DBG") && (size_t)nwg_dbg * 48 <= ((size_t)1 << 24) ? dbgbuf : nullptr;
 #endif
+    {
+        const unsigned dv[6] = {(unsigned)g.ncol, (unsigned)g.ncb, (unsigned)g.TH, (unsigned)g.C, (unsigned)(2 * g.C + 2), (unsigned)(2 * g.TH + 2)};
+        for (int i = 0; i < 6; ++i) set_magic(dv[i], g.dm[i], g.ds[i]);
+    }
     hipLaunchKernelGGL((wino_lds_kernel<NT, ACT, NP>), dim3(gm.nrb * gm.ncb * g.ncol), dim3(256), smem, st, g);
     YH_CHECK_LAUNCH("wino_lds");
 #ifdef YH_WINO_STAMPS
