@@ -16,4 +16,5 @@ for sz in n m l x; do
     env YH_BENCH_SIZE=$sz YH_BENCH_DTYPE=$dt $extra python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 > $O/ev_size_${sz}_${dt}.json 2> $O/ev_size_${sz}_${dt}.err
   done
 done
+python3 -c "import sys; sys.path.insert(0, 'tools'); from provenance import csrc_hash; print(csrc_hash())" > $O/collected_hash.txt
 echo refreshed

@@ -15,6 +15,11 @@ G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 
 def main():
     st = stamp()
+    # the files in gpurun_out/ must have been measured on THIS tree (refresh_evidence.sh records the hash it ran on): stamping the
+    # results of an earlier collection with the current hash would be a false provenance
+    ran_on = open(os.path.join(G, "collected_hash.txt")).read().strip() if os.path.exists(os.path.join(G, "collected_hash.txt")) else None
+    if ran_on != st["csrc_sha16"]:
+        sys.exit(f"gpurun_out/ev_* were collected on csrc hash {ran_on}, the tree is {st['csrc_sha16']}: run tools/refresh_evidence.sh on the GPU box first")
     for name in ("bench_f32", "bench_f32_80_640_64", "bench_f32_80_1280_16", "bench_bf16_1_640_64", "bench_bf16_80_640_64",
                  "bench_bf16_80_1280_16", "infer_latency"):
         d = json.load(open(os.path.join(G, f"ev_{name}.json")))
