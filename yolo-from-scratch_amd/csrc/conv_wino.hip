@@ -46,7 +46,6 @@ struct Wino {
     int TH, R, C, ncb;              // tile rows per image; tile rows x tile columns per workgroup (R C <= 32); column blocks per tile row
     unsigned dm[6];                 // division by multiplication (fdiv) for the block's index arithmetic: ncol, ncb, TH, C, 2 C + 2, 2 TH + 2
     int ds[6];
-    int st4;                        // the output view takes 16-byte stores (ldo % 4 == 0, 16-byte aligned): set by the launcher
     int PCh, plane, bufsz, toff_ofs;// half-row stride and plane stride of the patch (float4 units); one patch buffer, tile-offset table (floats)
 #ifdef YH_WINO_STAMPS
     unsigned long long *dbg;    // diagnostic build only: per-workgroup phase stamps
@@ -55,22 +54,6 @@ struct Wino {
 
 __device__ __forceinline__ int fdiv(int n, unsigned magic, int shift) {
     return shift < 0 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
-}
-
-// 4 x 4 transpose inside every lane quad: afterwards element k of lane i is what element i of lane k was.  Two exchange steps (with
-// lane ^ 2, then lane ^ 1), each a select of what to send, a DPP quad permutation and a select of where it lands.
-__device__ __forceinline__ float quad_xchg(float x, int ctrl_is_xor2) {
-    const int v = __builtin_bit_cast(int, x);
-    const int r = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false)     // quad_perm [2, 3, 0, 1]
-                               : __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1, 0, 3, 2]
-    return __builtin_bit_cast(float, r);
-}
-__device__ __forceinline__ void quad_transpose(float (&a)[4], bool b1, bool b0) {
-    float y;
-    y = quad_xchg(b1 ? a[0] : a[2], 1); if (b1) a[0] = y; else a[2] = y;
-    y = quad_xchg(b1 ? a[1] : a[3], 1); if (b1) a[1] = y; else a[3] = y;
-    y = quad_xchg(b0 ? a[0] : a[1], 0); if (b0) a[0] = y; else a[1] = y;
-    y = quad_xchg(b0 ? a[2] : a[3], 0); if (b0) a[2] = y; else a[3] = y;
 }
 
 // Output transform + store + BatchNorm partial sums.  `toff[32]` (LDS):
@@ -149,61 +132,6 @@ __device__ __forceinline__ void wino_epilogue(const Wino &g, f32x16 (&acc)[4][NT
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[j][r] = (L1[j][r] - L2[j][r]) - T[1][j][r];
         }
-        const int pc = (wave >> 1) * g.W + (wave & 1);
-        gfloat *const outg = yh_global(g.out);
-        const bool whole = whole_tiles && n0 + BNW <= g.N;                   // wave-uniform
-        if (whole && g.st4 && !(g.accumulate && g.stats)) {
-            // 16-BYTE STORES.  In the MFMA layout a lane holds ONE channel of four tiles per register group, so the direct form is 16 NT
-            // 4-byte stores per lane -- and a CU's address path takes a 64-lane memory instruction every 16 cycles whatever its width:
-            // in-kernel stamps put 4 500-4 900 of the epilogue's ~11 000 cycles on those 32 instructions per wave.  A 4 x 4 transpose
-            // inside each lane quad (DPP) turns a register group into FOUR consecutive channels of ONE tile per lane: 4 NT stores of
-            // 16 bytes.  The BatchNorm sums are taken before the transpose (lane = channel), in the order of the direct form.
-            float cs4[NT], cq4[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float bias = g.bias ? g.bias[n0 + 32 * j + lr] : 0.f;
-                cs4[j] = cq4[j] = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = Y[j][r] + bias;
-                    Y[j][r] = v;
-                    cs4[j] += v;
-                    cq4[j] += v * v;
-                }
-            }
-            const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
-            const int i4 = lr & 3, a4 = lr & ~3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tp0 = toff[8 * q + 4 * lh + i4];                    // this lane's tile of the group (all 32 slots hold tiles)
-                gfloat *const o0 = outg + (unsigned)((tp0 + pc) * g.ldo + n0 + a4);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    float a[4] = {Y[j][4 * q], Y[j][4 * q + 1], Y[j][4 * q + 2], Y[j][4 * q + 3]};
-                    quad_transpose(a, b1, b0);
-                    f32x4 v = {a[0], a[1], a[2], a[3]};
-                    YH_GLOBAL f32x4 *o = (YH_GLOBAL f32x4 *)(o0 + 32 * j);
-                    if (g.accumulate) v += *o;
-                    *o = v;
-                }
-            }
-            if (g.stats) {
-                float *red = smem + IMG_FLOATS + 32;                          // [4 waves][BNW][2]
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const float sm = cs4[j] + __shfl_xor(cs4[j], 32), q = cq4[j] + __shfl_xor(cq4[j], 32);
-                    if (lh == 0) { red[(wave * BNW + 32 * j + lr) * 2] = sm; red[(wave * BNW + 32 * j + lr) * 2 + 1] = q; }
-                }
-                __syncthreads();
-                if (t < BNW && n0 + t < g.N) {
-                    const float a0 = (red[t * 2] + red[(BNW + t) * 2]) + (red[(2 * BNW + t) * 2] + red[(3 * BNW + t) * 2]);
-                    const float a1 = (red[t * 2 + 1] + red[(BNW + t) * 2 + 1]) + (red[(2 * BNW + t) * 2 + 1] + red[(3 * BNW + t) * 2 + 1]);
-                    g.stats[((size_t)tgrp * 2 + 0) * g.N + n0 + t] = a0;
-                    g.stats[((size_t)tgrp * 2 + 1) * g.N + n0 + t] = a1;
-                }
-            }
-            return;
-        }
         // register r of this lane = tile (r & 3) + 8 (r >> 2) + 4 lh of the group: four consecutive offsets per 16-byte read
         int tp[16];
 #pragma unroll
@@ -211,6 +139,9 @@ __device__ __forceinline__ void wino_epilogue(const Wino &g, f32x16 (&acc)[4][NT
             const i32x4 x = *(const i32x4 *)(toff + 8 * q + 4 * lh);
             tp[4 * q] = x[0]; tp[4 * q + 1] = x[1]; tp[4 * q + 2] = x[2]; tp[4 * q + 3] = x[3];
         }
+        const int pc = (wave >> 1) * g.W + (wave & 1);
+        gfloat *const outg = yh_global(g.out);
+        const bool whole = whole_tiles && n0 + BNW <= g.N;                   // wave-uniform
         float cs[NT], cq[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -1140,7 +1071,6 @@ int launch_wino_lds(Wino &g, hipStream_t st) {
     WinoGeom gm{};
     YH_REQUIRE(wino_lds_geom(g.B, g.TH, g.TW, gm), "conv_wino: no block geometry for this shape");
     g.R = gm.R; g.C = gm.C; g.ncb = gm.ncb; g.PCh = gm.PCh; g.plane = gm.plane; g.bufsz = gm.bufsz;
-    g.st4 = (g.ldo % 4 == 0 && (((uintptr_t)g.out) & 15) == 0) ? 1 : 0;
     if (g.icoef) return g.N <= 32 ? launch_lds_nt<1, true>(g, gm, st) : launch_lds_nt<2, true>(g, gm, st);
     return g.N <= 32 ? launch_lds_nt<1, false>(g, gm, st) : launch_lds_nt<2, false>(g, gm, st);
 }
