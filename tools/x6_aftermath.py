@@ -52,6 +52,20 @@ def main():
         "wino 64->64 80^2": lambda: L.check(lib.yh_conv_wino_fwd(xw.data_ptr(), C, U.data_ptr(), C, None, yw.data_ptr(), C, pw_.data_ptr(), B, H, W, C, C, st)),
         "bn_silu_fwd 26 Mpx x 64": lambda: L.check(lib.yh_bn_silu_fwd(yw.data_ptr(), C, coef.data_ptr(), None, 0, out.data_ptr(), C, M, C, H, W, 0, st)),
     }
+    # steady state of ONE kind of launch: 40 back-to-back, time per launch (no other kernel in between)
+    for fname, ffn in front.items():
+        if fname == "nothing":
+            continue
+        for _ in range(10):
+            ffn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            ffn()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"steady state, 40 back-to-back {fname:9s}: {e0.elapsed_time(e1) / 40 * 1e3:7.1f} us per launch")
     for bname, bfn in behind.items():
         for fname, ffn in front.items():
             ffn(); bfn()
