@@ -420,6 +420,41 @@ def test_predict_batch_matches_oracle_pipeline_per_image(tmp_path):
     assert total_kept > 20
 
 
+def test_fused_and_unfused_plans_agree(monkeypatch):
+    """Round 4: consumers that apply their producer's BatchNorm + SiLU while staging (virtual layers: the normalised tensor never
+    exists) against the plan of the same model with every BatchNorm + SiLU pass launched (YH_FUSE_ACT=0, read when the plan is
+    traced).  Different kernels and summation orders, the same arithmetic: losses to 2e-6 relative, the whole gradient vector to 1e-4
+    relative (norm of the difference), every parameter tensor's gradient to cosine 1 - 1e-6; and the switch really switches."""
+    y = api()
+    nc, S, B = 3, 320, 4
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(31)).cuda()
+    tg = [t.cuda() for t in y.synthetic_targets(B, nc, S, 8, 32)]
+    runs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("YH_FUSE_ACT", fuse)
+        torch.manual_seed(0)
+        m = y.YOLO(num_classes=nc, img_size=S).cuda()
+        tr = y.HipTrainer(m, lr=1e-3, max_norm=None)
+        out = tr.step(x, tg)[:4].cpu().double()
+        plan = m._plan_for(x)
+        nvirt = sum(1 for r in plan.recs if getattr(r, "virtual", False))
+        grads = {n: p.grad.detach().double().reshape(-1).cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+        if not grads:                                     # the fused trainer keeps gradients in its flat buffer
+            off, grads = 0, {}
+            g = tr.flat_g.detach().double().cpu()
+            grads = {"flat": g.clone()}
+        runs[fuse] = (out, nvirt, grads)
+    monkeypatch.delenv("YH_FUSE_ACT")
+    assert runs["1"][1] >= 30 and runs["0"][1] == 0, (runs["1"][1], runs["0"][1])
+    a, b = runs["1"][0], runs["0"][0]
+    assert float(((a - b).abs() / b.abs().clamp_min(1e-12)).max()) <= 2e-6, (a, b)
+    for n in runs["1"][2]:
+        ga, gb = runs["1"][2][n], runs["0"][2][n]
+        assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm()) + 1e-12, n
+        if float(gb.norm()) > 1e-9:
+            assert float(ga @ gb / (ga.norm() * gb.norm())) >= 1 - 1e-6, n
+
+
 def test_side_lanes_do_not_change_results_and_trajectory_tracks_oracle():
     """(i) fork/join lanes are a pure scheduling change: parameters after 3 steps are bitwise identical with the
     side stream disabled; (ii) a 3-step trajectory (clip + Adam each step) tracks the CPU oracle's losses."""
